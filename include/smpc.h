@@ -1,0 +1,235 @@
+/*
+ * smpc.h -- C ABI of the MI355X batched safe-MPC engine.
+ *
+ * This is the drop-in boundary for ONE path of idra-lab/safe-mpc: everything at and below
+ * AbstractController.solve() (reference src/safe_mpc/controller.py:136-167), i.e. what the reference
+ * reaches through acados_template.AcadosOcpSolver (controller.py:247) -- batched over independent OCP
+ * instances.  Plain pointers and sizes only; no torch / numpy types.  The same structs are mirrored with
+ * ctypes in safe_mpc_amd/problem.py and are also read by the test oracle (oracle/), which shares this
+ * interface and nothing else with the product.
+ *
+ * Conventions
+ *   - all arrays are row-major and laid out exactly like the reference's numpy arrays:
+ *       x0 [B][nx], x_guess [B][N+1][nx], u_guess [B][N][nu], p [B][N+1][5]   (guess_acados.py:236,
+ *       controller.py:147-156); nx = 2*nq, nu = nq, p = [ee_ref(3), alpha, flag] (controller.py:27-31).
+ *   - every entry point returns 0 on success and a negative SMPC_E* code on API misuse / HIP failure.
+ *     The numerical outcome of each instance is reported only through status[B], using the acados codes the
+ *     reference tests against (0 ok, 1 NaN, 2 max-iter, 3 min-step, 4 QP failure; controller.py:125,158).
+ *   - a handle is bound to one device and one stream, owns all device scratch, and is not thread-safe.
+ */
+#ifndef SMPC_H_
+#define SMPC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMPC_ABI_VERSION 1
+
+#define SMPC_MAX_NQ 7
+#define SMPC_MAX_NX 14
+#define SMPC_MAX_POINTS 12
+#define SMPC_MAX_ROWS 12
+#define SMPC_MAX_LAYERS 6
+#define SMPC_MAX_N 63
+#define SMPC_NP 5 /* per-node parameter vector length */
+
+/* bounds with |value| >= SMPC_INF are treated as absent (the reference writes 1e6 for "no upper bound",
+ * env_model.py:265-266, safe_set.py:104) */
+#define SMPC_INF 1.0e5
+
+/* error codes */
+#define SMPC_OK 0
+#define SMPC_EINVAL (-1)
+#define SMPC_ENOMEM (-2)
+#define SMPC_EHIP (-3)
+#define SMPC_ESTATE (-4)
+
+/* acados status codes reproduced per instance */
+#define SMPC_STATUS_SUCCESS 0
+#define SMPC_STATUS_NAN 1
+#define SMPC_STATUS_MAXITER 2
+#define SMPC_STATUS_MINSTEP 3
+#define SMPC_STATUS_QP_FAILURE 4
+
+/* One actuated revolute joint and the (lumped) link it moves.  Replaces the adam KinDynComputations model the
+ * reference builds from the URDF (env_model.py:40-45).  Links reached through fixed / locked joints are lumped
+ * into `mass, com, inertia` by the host (safe_mpc_amd/urdf.py). */
+typedef struct {
+    double R0[9];      /* parent-link frame -> joint frame rotation at q = 0, row-major (URDF origin rpy) */
+    double p0[3];      /* ... and translation (URDF origin xyz) */
+    double axis[3];    /* unit axis in the joint (= child link) frame */
+    double mass;       /* lumped mass of the child link */
+    double com[3];     /* lumped centre of mass, child-link frame */
+    double inertia[6]; /* ixx ixy ixz iyy iyz izz about the COM, child-link axes */
+    double q_min, q_max, v_max, tau_max; /* URDF <limit> (env_model.py:107-114) */
+} smpc_joint;
+
+/* A point rigidly attached to the child link of actuated joint `link` (link = -1: fixed in the world). */
+typedef struct {
+    int32_t link;
+    int32_t reserved;
+    double local[3];
+} smpc_point;
+
+/* kinds of collision rows (env_model.py:263-316) */
+#define SMPC_ROW_SEG_FIXEDSEG 0 /* capsule-capsule, second capsule fixed (utils.py:94-113) */
+#define SMPC_ROW_SEG_SEG 1      /* capsule-capsule, both on the robot */
+#define SMPC_ROW_SEG_POINT 2    /* capsule-sphere (utils.py:115-118) */
+#define SMPC_ROW_POINT_POINT 3  /* sphere-sphere on the EE point (env_model.py:300-301) */
+#define SMPC_ROW_COORD 4        /* plane: coordinate of a robot point (env_model.py:286-287, utils.py:123-124) */
+
+typedef struct {
+    int32_t kind;
+    int32_t pa, pb; /* robot points: segment A-B, or the single point pa */
+    int32_t pc, pd; /* second robot segment (SEG_SEG) */
+    int32_t axis;   /* COORD: 0/1/2 */
+    double C[3];    /* fixed segment start / fixed point */
+    double D[3];    /* fixed segment end */
+    double len2;    /* SEG_POINT: capsule_length**2 used as denominator (utils.py:116) */
+    double offset;  /* COORD: value = P[axis] - offset */
+    double lb, ub;  /* lh, uh of this row */
+} smpc_row;
+
+#define SMPC_COST_ZERO 0  /* ZeroCost (cost_definition.py:34-46) */
+#define SMPC_COST_REACH 1 /* ReachTargetEXT / ReachTargetNLS (cost_definition.py:61-100) */
+
+#define SMPC_HESS_GAUSS_NEWTON 0 /* NONLINEAR_LS */
+#define SMPC_HESS_EXACT 1        /* EXTERNAL + hessian_approx EXACT (cost_definition.py:18,100) */
+
+#define SMPC_NN_NONE 0
+#define SMPC_NN_TERMINAL 1 /* ST / HTWA / RealReceding: node N only (controller.py:332-357) */
+#define SMPC_NN_ALL 2      /* Receding / constraint_everywhere: nodes 1..N, switched by p[4] (controller.py:411-442) */
+
+typedef struct {
+    int32_t abi_version;
+    int32_t nq;
+    int32_t N;
+    int32_t n_points;
+    int32_t n_rows;
+    int32_t ee_point;          /* index of the EE point (env_model.py:92-95) */
+    int32_t cost_kind;
+    int32_t hessian;
+    int32_t nn_mode;
+    int32_t nn_dof;            /* n_dof_safe_set (config.yaml:11) */
+    int32_t qp_max_iter;       /* qp_solver_iter_max (config.yaml:18) */
+    int32_t reserved0;
+    double dt;                 /* config.yaml:7 */
+    double Q, R;               /* config.yaml:35,39 */
+    double cost_scale_stage;   /* acados multiplies stage costs by dt, terminal by 1 [EXT-UNVERIFIED] */
+    double cost_scale_term;
+    double lm_stage;           /* Levenberg-Marquardt added to every diagonal of the stage Hessian */
+    double lm_term;
+    double nn_eps;             /* config.yaml:48 */
+    double nn_soft_e;          /* L1 slack weight on the terminal NN row (zl_e, controller.py:348-354); < 0 = hard */
+    double nn_soft_run;        /* same for running nodes; < 0 = hard */
+    double qp_tol;             /* IPM exit tolerance on residuals and complementarity */
+    double qp_mu0;             /* IPM initial barrier */
+    double gravity[3];
+    double nn_mean[SMPC_MAX_NQ];
+    double nn_std[SMPC_MAX_NQ];
+    double x_lo[SMPC_MAX_NX];   /* lbx / ubx of nodes 1..N-1 (controller.py:49-51) */
+    double x_hi[SMPC_MAX_NX];
+    double x_lo_e[SMPC_MAX_NX]; /* lbx_e / ubx_e (controller.py:53-55, 300-306) */
+    double x_hi_e[SMPC_MAX_NX];
+    smpc_joint joints[SMPC_MAX_NQ];
+    smpc_point points[SMPC_MAX_POINTS];
+    smpc_row rows[SMPC_MAX_ROWS];
+} smpc_problem_desc;
+
+/* Per-(instance, node) linearisation record returned by smpc_eval_nodes; one per node k = 0..N.
+ * Exposes what acados evaluates through the CasADi-generated functions (N2 in SURVEY section 2) so that each piece
+ * can be compared with the oracle separately. */
+typedef struct {
+    double tau[SMPC_MAX_NQ];                       /* M(q)u + h(q,qd) (env_model.py:80-83) */
+    double M[SMPC_MAX_NQ * SMPC_MAX_NQ];           /* dtau/du, row-major nq x nq (leading dim nq) */
+    double dtau_dq[SMPC_MAX_NQ * SMPC_MAX_NQ];
+    double dtau_dv[SMPC_MAX_NQ * SMPC_MAX_NQ];
+    double ee[3];                                  /* t_glob (env_model.py:92-95) */
+    double cost_grad_q[SMPC_MAX_NQ];               /* d/dq of Q*|ee - ref|^2 (unscaled) */
+    double cost_hess_qq[SMPC_MAX_NQ * SMPC_MAX_NQ];/* exact or Gauss-Newton, unscaled, row-major */
+    double row_val[SMPC_MAX_ROWS];                 /* collision rows */
+    double row_grad[SMPC_MAX_ROWS * SMPC_MAX_NQ];  /* d row / dq, row-major n_rows x nq */
+    double nn_val;                                 /* g(x,p) (safe_set.py:94), 0 if not evaluated */
+    double nn_grad[SMPC_MAX_NX];                   /* dg/dx */
+} smpc_node_eval;
+
+typedef struct smpc_handle smpc_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------- */
+/* replaces AcadosOcpSolver(ocp, json_file, generate, build) (controller.py:247); device = HIP device ordinal */
+int smpc_create(const smpc_problem_desc* desc, int device, smpc_handle** out);
+void smpc_destroy(smpc_handle* h);
+int smpc_abi_version(void);
+/* last error text of this handle (or of the failed smpc_create when h == NULL) */
+const char* smpc_last_error(const smpc_handle* h);
+
+/* replaces l4c.L4CasADi(model_net, device='cpu') + model_external_shared_lib_* (safe_set.py:89-94,
+ * controller.py:344-346): fp32 weights W[l] is [dims[l+1]][dims[l]] row-major (torch nn.Linear.weight), b[l] is
+ * [dims[l+1]]; activation between layers is GELU(tanh) (parser.py:99), none after the last.  Pointers may be host or
+ * device memory (on_device != 0: e.g. torch.Tensor.data_ptr() of a ROCm tensor); the handle keeps its own copy. */
+int smpc_set_mlp(smpc_handle* h, int nlayers, const int32_t* dims, const float* const* W, const float* const* b,
+                 int on_device);
+
+/* replaces ocp_solver.set_new_time_steps + update_qp_solver_cond_N (controller.py:208-209): change N without
+ * re-creating; N <= SMPC_MAX_N */
+int smpc_set_horizon(smpc_handle* h, int N);
+
+/* replaces ocp_solver.constraints_set(k,'lbx'/'ubx',v) for k >= 1 (controller.py:531-536).  lo/hi are [N+1][nx]
+ * shared by all instances, or NULL to restore the descriptor's bounds. */
+int smpc_set_stage_bounds(smpc_handle* h, const double* lo, const double* hi);
+
+/* ---- the hot path --------------------------------------------------------------------------------------------- */
+/* One SQP-RTI solve of B independent OCPs: replaces reset / constraints_set(0,lbx|ubx,x0) / set(i,x|u|p) / solve /
+ * get(i,x|u) of controller.py:141-164 for B instances in one call.
+ *   x0 [B][nx], xg [B][N+1][nx], ug [B][N][nu], p [B][N+1][5]        inputs
+ *   x_out [B][N+1][nx], u_out [B][N][nu], status [B], qp_iter [B]    outputs (qp_iter may be NULL)
+ * on_device != 0: all pointers are device pointers (resident in HBM); the call only enqueues work on the handle's
+ * stream (use smpc_sync to wait).  on_device == 0: host pointers; the call copies in, runs, copies out and waits. */
+int smpc_solve_batch(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
+                     double* x_out, double* u_out, int32_t* status, int32_t* qp_iter, int on_device);
+
+/* Linearisation only (HOT LOOP A of SURVEY 3.2): evaluates every node of every instance at (xg, ug, p) and writes
+ * out[B][N+1] records.  Used by the parity tests; pointers follow on_device like smpc_solve_batch. */
+int smpc_eval_nodes(smpc_handle* h, int B, const double* xg, const double* ug, const double* p, smpc_node_eval* out,
+                    int on_device);
+
+/* ---- callers on either side of the solve ------------------------------------------- */
+/* guessCorrection (controller.py:226-231): x_guess[k+1] = f(x_guess[k], u_guess[k]) in place. */
+int smpc_guess_correction(smpc_handle* h, int B, double* xg, const double* ug, int on_device);
+
+/* provideControl (controller.py:169-184): per instance, take (x_temp,u_temp) if accept[b] != 0 else keep the old
+ * guess; write u_apply = row 0; shift by one and duplicate the last row. */
+int smpc_provide_control(smpc_handle* h, int B, const int32_t* accept, const double* x_temp, const double* u_temp,
+                         double* xg, double* ug, double* u_apply, int on_device);
+
+/* checkStateConstraints over a trajectory (env_model.py:170-173, 236-243): ok[b] = all nodes within
+ * [x_min - tol_x, x_max + tol_x] (the margin-widened model bounds passed here) and collision rows within
+ * [lb_chk, ub_chk]; nn_ok[b][k] = g(x_k, alpha) >= -tol_safe (safe_set.py:61-68) if nn_ok != NULL. */
+int smpc_check_trajectory(smpc_handle* h, int B, int n_nodes, const double* x, const double* x_min,
+                          const double* x_max, double tol_x, const double* row_lb_chk, const double* row_ub_chk,
+                          double alpha, double tol_safe, int32_t* state_ok, int32_t* nn_ok, int on_device);
+
+/* plant step AdamModel.integrate (env_model.py:192-206): tau = RNEA_noisy(x,u) + noise, clip, qdd = M^-1(tau - h),
+ * double-integrator step.  joints_noisy is [B][nq] smpc_joint (per-instance perturbed inertials) or NULL for the
+ * nominal model; tau_noise [B][nq] additive torque noise or NULL. */
+int smpc_plant_step(smpc_handle* h, int B, const double* x, const double* u, const smpc_joint* joints_noisy,
+                    const double* tau_noise, double* x_next, double* u_eff, int on_device);
+
+/* wait for the handle's stream */
+int smpc_sync(smpc_handle* h);
+/* the hipStream_t the handle enqueues on (for event timing by the caller) */
+void* smpc_stream(smpc_handle* h);
+/* device time of the kernels of the last smpc_solve_batch, measured with HIP events on the handle's stream:
+ * ms[0] linearise, ms[1] MLP, ms[2] QP, ms[3] total.  Mirrors ocp_solver.get_stats('time_lin'|'time_qp'|'time_tot')
+ * (controller.py:123-124,192-193).  Only valid when timing was enabled. */
+int smpc_enable_timing(smpc_handle* h, int on);
+int smpc_get_timing(smpc_handle* h, float* ms4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMPC_H_ */

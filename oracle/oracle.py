@@ -1,0 +1,201 @@
+"""ctypes loader for the CPU oracle (oracle/smpc_oracle.cpp).  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from safe_mpc_amd/.
+PARITY UNPINNED: see the header of smpc_oracle.cpp.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, 'libsmpc_oracle.so')
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'smpc_oracle.cpp')
+    hdr = os.path.join(_HERE, '..', 'include', 'smpc.h')
+    if (not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= os.path.getmtime(src)
+            and os.path.getmtime(_LIB) >= os.path.getmtime(hdr)):
+        return _LIB
+    subprocess.check_call(['make', '-C', _HERE, '-B', 'libsmpc_oracle.so'], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_create.restype = C.c_void_p
+        _lib.orc_segment_dist2.restype = C.c_double
+    return _lib
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """CPU restatement of the engine behind the same problem descriptor."""
+
+    def __init__(self, problem, mlp=None):
+        from safe_mpc_amd.problem import NODE_EVAL_DTYPE  # struct mirrors only (interface, not implementation)
+        self._ne = NODE_EVAL_DTYPE
+        self.L = lib()
+        self.problem = problem
+        self.h = C.c_void_p(self.L.orc_create(C.byref(problem.desc)))
+        if not self.h:
+            raise RuntimeError('orc_create failed')
+        self.nq, self.nx, self.nu = problem.nq, problem.nx, problem.nu
+        self.N = problem.N
+        if mlp is not None:
+            self.set_mlp(*mlp)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_mlp(self, weights, biases):
+        n = len(weights)
+        Ws = [np.ascontiguousarray(w, np.float32) for w in weights]
+        bs = [np.ascontiguousarray(b, np.float32) for b in biases]
+        dims = np.array([Ws[0].shape[1]] + [w.shape[0] for w in Ws], np.int32)
+        Wp = (C.POINTER(C.c_float) * n)(*[_p(w, C.c_float) for w in Ws])
+        bp = (C.POINTER(C.c_float) * n)(*[_p(b, C.c_float) for b in bs])
+        rc = self.L.orc_set_mlp(self.h, n, _p(dims, C.c_int32), Wp, bp)
+        assert rc == 0
+
+    def set_horizon(self, N):
+        assert self.L.orc_set_horizon(self.h, int(N)) == 0
+        self.N = int(N)
+
+    def set_stage_bounds(self, lo, hi):
+        if lo is None:
+            self.L.orc_set_stage_bounds(self.h, None, None)
+        else:
+            lo, hi = _f64(lo), _f64(hi)
+            assert lo.shape == (self.N + 1, self.nx)
+            self.L.orc_set_stage_bounds(self.h, _p(lo), _p(hi))
+
+    # -- components ---------------------------------------------------------------------------------------------------
+    def rnea(self, q, qd, qdd):
+        q, qd, qdd = _f64(q), _f64(qd), _f64(qdd)
+        tau = np.zeros(self.nq)
+        self.L.orc_rnea(self.h, _p(q), _p(qd), _p(qdd), _p(tau))
+        return tau
+
+    def fk(self, q):
+        q = _f64(q)
+        R, p = np.zeros((self.nq, 3, 3)), np.zeros((self.nq, 3))
+        self.L.orc_fk(self.h, _p(q), _p(R), _p(p))
+        return R, p
+
+    def points(self, q):
+        q = _f64(q)
+        out = np.zeros((self.problem.desc.n_points, 3))
+        self.L.orc_points(self.h, _p(q), _p(out))
+        return out
+
+    def segment_dist2(self, A, B, Cc, D):
+        A, B, Cc, D = _f64(A), _f64(B), _f64(Cc), _f64(D)
+        return float(self.L.orc_segment_dist2(_p(A), _p(B), _p(Cc), _p(D)))
+
+    def mlp(self, s):
+        s = np.ascontiguousarray(s, np.float32)
+        y = np.zeros(1, np.float32)
+        g = np.zeros(s.shape[0], np.float32)
+        self.L.orc_mlp(self.h, _p(s, C.c_float), _p(y, C.c_float), _p(g, C.c_float))
+        return float(y[0]), g
+
+    def nn_row(self, x, alpha):
+        x = _f64(x)
+        g = np.zeros(1)
+        dg = np.zeros(self.nx)
+        self.L.orc_nn_row(self.h, _p(x), C.c_double(alpha), _p(g), _p(dg))
+        return float(g[0]), dg
+
+    def eval_nodes(self, xg, ug, p):
+        xg, ug, p = _f64(xg), _f64(ug), _f64(p)
+        B = xg.shape[0]
+        out = np.zeros((B, self.N + 1), self._ne)
+        self.L.orc_eval_nodes(self.h, B, _p(xg), _p(ug), _p(p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    # -- hot path -----------------------------------------------------------------------------------------------------
+    def solve_batch(self, x0, xg, ug, p, with_res=False):
+        x0, xg, ug, p = _f64(x0), _f64(xg), _f64(ug), _f64(p)
+        B = x0.shape[0]
+        assert xg.shape == (B, self.N + 1, self.nx) and ug.shape == (B, self.N, self.nu) and p.shape == (B, self.N + 1, 5)
+        xo, uo = np.zeros_like(xg), np.zeros_like(ug)
+        st, it = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        res = np.zeros((B, 2))
+        self.L.orc_solve_batch(self.h, B, _p(x0), _p(xg), _p(ug), _p(p), _p(xo), _p(uo), _p(st, C.c_int32),
+                               _p(it, C.c_int32), _p(res))
+        if with_res:
+            return xo, uo, st, it, res
+        return xo, uo, st, it
+
+    def build_qp(self, x0, xg, ug, p):
+        """Stage QP of ONE instance as dense numpy blocks (for independent solvers in the tests)."""
+        mz, mx, mr = C.c_int(), C.c_int(), C.c_int()
+        self.L.orc_qp_dims(C.byref(mz), C.byref(mx), C.byref(mr))
+        mz, mx, mr = mz.value, mx.value, mr.value
+        N = self.N
+        x0, xg, ug, p = _f64(x0), _f64(xg), _f64(ug), _f64(p)
+        H = np.zeros((N + 1, mz, mz)); g = np.zeros((N + 1, mz)); b = np.zeros((N + 1, mx))
+        Cm = np.zeros((N + 1, mr, mz)); lo = np.zeros((N + 1, mr)); hi = np.zeros((N + 1, mr))
+        hl = np.zeros((N + 1, mr), np.int32); hh = np.zeros((N + 1, mr), np.int32)
+        soft = np.zeros((N + 1, mr)); nr = np.zeros(N + 1, np.int32); dx0 = np.zeros(mx)
+        self.L.orc_build_qp(self.h, _p(x0), _p(xg), _p(ug), _p(p), _p(H), _p(g), _p(b), _p(Cm), _p(lo), _p(hi),
+                            _p(hl, C.c_int32), _p(hh, C.c_int32), _p(soft), _p(nr, C.c_int32), _p(dx0))
+        return dict(H=H, g=g, b=b, C=Cm, lo=lo, hi=hi, has_lo=hl.astype(bool), has_hi=hh.astype(bool), soft=soft,
+                    nr=nr, dx0=dx0[:self.nx])
+
+    # -- callers ------------------------------------------------------------------------------------------------------
+    def guess_correction(self, xg, ug):
+        xg = _f64(xg).copy()
+        ug = _f64(ug)
+        self.L.orc_guess_correction(self.h, xg.shape[0], _p(xg), _p(ug))
+        return xg
+
+    def provide_control(self, accept, xt, ut, xg, ug):
+        accept = np.ascontiguousarray(accept, np.int32)
+        xt, ut = _f64(xt), _f64(ut)
+        xg, ug = _f64(xg).copy(), _f64(ug).copy()
+        ua = np.zeros((xg.shape[0], self.nu))
+        self.L.orc_provide_control(self.h, xg.shape[0], _p(accept, C.c_int32), _p(xt), _p(ut), _p(xg), _p(ug), _p(ua))
+        return xg, ug, ua
+
+    def check_trajectory(self, x, x_min, x_max, tol_x, row_lb, row_ub, alpha=0.0, tol_safe=0.0, want_nn=False):
+        x = _f64(x)
+        B, n_nodes = x.shape[0], x.shape[1]
+        ok = np.zeros(B, np.int32)
+        nn_ok = np.zeros((B, n_nodes), np.int32) if want_nn else None
+        self.L.orc_check_trajectory(self.h, B, n_nodes, _p(x), _p(_f64(x_min)), _p(_f64(x_max)), C.c_double(tol_x),
+                                    _p(_f64(row_lb)), _p(_f64(row_ub)), C.c_double(alpha), C.c_double(tol_safe),
+                                    _p(ok, C.c_int32), _p(nn_ok, C.c_int32) if want_nn else None)
+        return (ok.astype(bool), nn_ok.astype(bool)) if want_nn else ok.astype(bool)
+
+    def plant_step(self, x, u, joints_noisy=None, tau_noise=None):
+        x, u = _f64(x), _f64(u)
+        B = x.shape[0]
+        xn, ue = np.zeros_like(x), np.zeros_like(u)
+        jn = joints_noisy.ctypes.data_as(C.c_void_p) if joints_noisy is not None else None
+        tn = _p(_f64(tau_noise)) if tau_noise is not None else None
+        self.L.orc_plant_step(self.h, B, _p(x), _p(u), jn, tn, _p(xn), _p(ue))
+        return xn, ue
