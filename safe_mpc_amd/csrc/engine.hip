@@ -1,0 +1,624 @@
+// engine.hip -- C ABI (include/smpc.h) of the MI355X batched safe-MPC engine: handle, device buffers, kernel launches.
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC engine.hip -o libsmpc_hip.so
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/smpc.h"
+#include "kernel_qp.hpp"
+#include "kernels_callers.hpp"
+#include "kernels_mlp.hpp"
+#include "kernels_nodes.hpp"
+
+using namespace smpc;
+
+namespace {
+thread_local char g_create_err[256] = "";
+}
+
+struct smpc_handle {
+    smpc_problem_desc desc;
+    int device = 0;
+    int N = 0;
+    hipStream_t stream = nullptr;
+    smpc_problem_desc* d_desc = nullptr;
+    double *d_lo = nullptr, *d_hi = nullptr;  // [N+1][nx] stage bounds
+    // network
+    int nlayers = 0;
+    int dims[SMPC_MAX_LAYERS + 1] = {0};
+    int H = 0;
+    float* d_Wfwd[SMPC_MAX_LAYERS] = {nullptr};  // [K][N] = W^T (layer 0 padded to MLP_KPAD rows)
+    float* d_Wbwd[SMPC_MAX_LAYERS] = {nullptr};  // [out][in] as given (layer 0 padded to MLP_NPAD columns)
+    float* d_bias[SMPC_MAX_LAYERS] = {nullptr};
+    // per-batch scratch, grown on demand
+    int capB = 0;
+    smpc_node_eval* d_ev = nullptr;
+    double* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    // staging for host-pointer calls
+    int capIO = 0;
+    double *d_x0 = nullptr, *d_xg = nullptr, *d_ug = nullptr, *d_p = nullptr, *d_xo = nullptr, *d_uo = nullptr;
+    int32_t *d_st = nullptr, *d_it = nullptr;
+    // MLP activations
+    size_t capM = 0;
+    float *d_S = nullptr, *d_y = nullptr, *d_GS = nullptr, *d_dA = nullptr, *d_dB = nullptr;
+    float* d_act[SMPC_MAX_LAYERS] = {nullptr};
+    float* d_dg[SMPC_MAX_LAYERS] = {nullptr};
+    // generic scratch for the caller entry points
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    // timing
+    int timing = 0;
+    hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float last_ms[4] = {0, 0, 0, 0};
+    char err[256] = "";
+};
+
+namespace {
+
+int fail(smpc_handle* h, int code, const char* fmt, ...) {
+    char* dst = h ? h->err : g_create_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 256, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(h, expr)                                                                                       \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return fail(h, SMPC_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+template <class T> int dev_alloc(smpc_handle* h, T** p, size_t count) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (count == 0) return SMPC_OK;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(h, SMPC_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    }
+    return SMPC_OK;
+}
+
+size_t ws_doubles_per_instance(const smpc_problem_desc& d, int N) {
+    switch (d.nq) {
+    case 5: return QpLayout<5>(d.n_rows).per_instance(N);
+    case 6: return QpLayout<6>(d.n_rows).per_instance(N);
+    default: return QpLayout<7>(d.n_rows).per_instance(N);
+    }
+}
+
+int upload_bounds(smpc_handle* h, const double* lo, const double* hi) {
+    const int nx = 2 * h->desc.nq;
+    std::vector<double> l((size_t)(h->N + 1) * nx), u((size_t)(h->N + 1) * nx);
+    for (int k = 0; k <= h->N; k++)
+        for (int i = 0; i < nx; i++) {
+            l[(size_t)k * nx + i] = lo ? lo[(size_t)k * nx + i] : (k == h->N ? h->desc.x_lo_e[i] : h->desc.x_lo[i]);
+            u[(size_t)k * nx + i] = hi ? hi[(size_t)k * nx + i] : (k == h->N ? h->desc.x_hi_e[i] : h->desc.x_hi[i]);
+        }
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_lo, l.size()))) return rc;
+    if ((rc = dev_alloc(h, &h->d_hi, u.size()))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_lo, l.data(), l.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_hi, u.data(), u.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SMPC_OK;
+}
+
+int ensure_batch(smpc_handle* h, int B) {
+    const size_t per = ws_doubles_per_instance(h->desc, h->N);
+    const size_t need = per * (size_t)B * sizeof(double);
+    if (B > h->capB || need > h->ws_bytes) {
+        int rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if ((rc = dev_alloc(h, &h->d_ev, (size_t)B * (SMPC_MAX_N + 1)))) return rc;
+        if ((rc = dev_alloc(h, &h->d_ws, per * (size_t)B))) return rc;
+        h->ws_bytes = need;
+        h->capB = B;
+        h->capIO = 0;
+    }
+    return SMPC_OK;
+}
+
+int ensure_io(smpc_handle* h, int B) {
+    if (B <= h->capIO) return SMPC_OK;
+    const int nx = 2 * h->desc.nq, nu = h->desc.nq, NN = SMPC_MAX_N;
+    int rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = dev_alloc(h, &h->d_x0, (size_t)B * nx))) return rc;
+    if ((rc = dev_alloc(h, &h->d_xg, (size_t)B * (NN + 1) * nx))) return rc;
+    if ((rc = dev_alloc(h, &h->d_ug, (size_t)B * NN * nu))) return rc;
+    if ((rc = dev_alloc(h, &h->d_p, (size_t)B * (NN + 1) * SMPC_NP))) return rc;
+    if ((rc = dev_alloc(h, &h->d_xo, (size_t)B * (NN + 1) * nx))) return rc;
+    if ((rc = dev_alloc(h, &h->d_uo, (size_t)B * NN * nu))) return rc;
+    if ((rc = dev_alloc(h, &h->d_st, (size_t)B))) return rc;
+    if ((rc = dev_alloc(h, &h->d_it, (size_t)B))) return rc;
+    h->capIO = B;
+    return SMPC_OK;
+}
+
+int ensure_tmp(smpc_handle* h, size_t bytes) {
+    if (bytes <= h->tmp_bytes) return SMPC_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_tmp) { (void)hipFree(h->d_tmp); h->d_tmp = nullptr; }
+    hipError_t e = hipMalloc(&h->d_tmp, bytes);
+    if (e != hipSuccess) return fail(h, SMPC_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    h->tmp_bytes = bytes;
+    return SMPC_OK;
+}
+
+int ensure_mlp(smpc_handle* h, size_t M) {
+    const size_t Mp = (M + 127) / 128 * 128;
+    if (Mp <= h->capM) return SMPC_OK;
+    int rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const size_t H = h->H;
+    if ((rc = dev_alloc(h, &h->d_S, Mp * MLP_KPAD))) return rc;
+    if ((rc = dev_alloc(h, &h->d_y, Mp))) return rc;
+    if ((rc = dev_alloc(h, &h->d_GS, Mp * MLP_NPAD))) return rc;
+    if ((rc = dev_alloc(h, &h->d_dA, Mp * H))) return rc;
+    if ((rc = dev_alloc(h, &h->d_dB, Mp * H))) return rc;
+    for (int l = 0; l + 1 < h->nlayers; l++) {
+        if ((rc = dev_alloc(h, &h->d_act[l], Mp * H))) return rc;
+        if ((rc = dev_alloc(h, &h->d_dg[l], Mp * H))) return rc;
+    }
+    h->capM = Mp;
+    return SMPC_OK;
+}
+
+// forward (and optionally backward) pass of the network over M rows whose states are found through (mode, N) in x
+template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const double* d_x, bool backward) {
+    int rc;
+    if ((rc = ensure_mlp(h, (size_t)M))) return rc;
+    const int Mp = (M + 127) / 128 * 128, H = h->H, L = h->nlayers;
+    hipStream_t s = h->stream;
+    hipLaunchKernelGGL((k_nn_features<NQ>), dim3((Mp + 255) / 256), dim3(256), 0, s, h->d_desc, M, Mp, N, mode, d_x,
+                       h->d_S);
+    const dim3 blk(256), grd(Mp / 128, H / 64);
+    hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, MLP_KPAD, h->d_S, h->d_Wfwd[0], h->d_bias[0],
+                       (const float*)nullptr, h->d_act[0], h->d_dg[0]);
+    for (int l = 1; l + 1 < L; l++)
+        hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
+                           h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l]);
+    hipLaunchKernelGGL(k_nn_output, dim3((Mp + 3) / 4), blk, 0, s, Mp, H, h->d_act[L - 2], h->d_dg[L - 2],
+                       h->d_Wbwd[L - 1], h->d_bias[L - 1], h->d_y, h->d_dA);
+    if (backward) {
+        float *cur = h->d_dA, *nxt = h->d_dB;
+        for (int l = L - 2; l >= 1; l--) {
+            hipLaunchKernelGGL((k_gemm_f32<EPI_MUL>), grd, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l], (const float*)nullptr,
+                               h->d_dg[l - 1], nxt, (float*)nullptr);
+            float* t = cur; cur = nxt; nxt = t;
+        }
+        hipLaunchKernelGGL((k_gemm_f32<EPI_PLAIN>), dim3(Mp / 128, MLP_NPAD / 64), blk, 0, s, Mp, MLP_NPAD, H, cur,
+                           h->d_Wbwd[0], (const float*)nullptr, (const float*)nullptr, h->d_GS, (float*)nullptr);
+    }
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
+}
+
+template <int NQ>
+int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, const double* d_p, smpc_node_eval* d_ev) {
+    const int N = h->N;
+    hipStream_t s = h->stream;
+    const long n1 = (long)B * (N + 1), n2 = (long)B * N;
+    hipLaunchKernelGGL((k_node_geometry<NQ>), dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, s, h->d_desc, B, N, d_xg,
+                       d_p, d_ev);
+    hipLaunchKernelGGL((k_node_torque<NQ>), dim3((unsigned)((n2 + 127) / 128), 3 * NQ), dim3(128), 0, s, h->d_desc, B, N,
+                       d_xg, d_ug, d_ev);
+    HIPCHK(h, hipGetLastError());
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
+    if (h->desc.nn_mode != SMPC_NN_NONE) {
+        if (h->nlayers == 0) return fail(h, SMPC_ESTATE, "nn_mode != NONE but smpc_set_mlp was not called");
+        const int mode = h->desc.nn_mode == SMPC_NN_TERMINAL ? 1 : 2;
+        const int M = mode == 1 ? B : B * N;
+        int rc;
+        if ((rc = run_mlp<NQ>(h, M, mode, N, d_xg, true))) return rc;
+        hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 255) / 256), dim3(256), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
+                           h->d_y, h->d_GS, d_ev);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[2], s));
+    return SMPC_OK;
+}
+
+template <int NQ>
+int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
+                 double* xo, double* uo, int32_t* st, int32_t* it) {
+    int rc;
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
+    if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev))) return rc;
+    hipLaunchKernelGGL((k_qp_ipm<NQ>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, h->d_lo,
+                       h->d_hi, h->d_ev, h->d_ws, xo, uo, st, it);
+    HIPCHK(h, hipGetLastError());
+    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream));
+    return SMPC_OK;
+}
+
+#define DISPATCH_NQ(h, call)                                                      \
+    switch ((h)->desc.nq) {                                                       \
+    case 5: { constexpr int NQ_ = 5; rc = call; } break;                          \
+    case 6: { constexpr int NQ_ = 6; rc = call; } break;                          \
+    case 7: { constexpr int NQ_ = 7; rc = call; } break;                          \
+    default: rc = fail(h, SMPC_EINVAL, "nq=%d not built (5, 6, 7)", (h)->desc.nq); \
+    }
+
+}  // namespace
+
+extern "C" {
+
+int smpc_abi_version(void) { return SMPC_ABI_VERSION; }
+
+const char* smpc_last_error(const smpc_handle* h) { return h ? h->err : g_create_err; }
+
+int smpc_create(const smpc_problem_desc* desc, int device, smpc_handle** out) {
+    if (!desc || !out) return fail(nullptr, SMPC_EINVAL, "null argument");
+    *out = nullptr;
+    if (desc->abi_version != SMPC_ABI_VERSION)
+        return fail(nullptr, SMPC_EINVAL, "descriptor ABI %d, library ABI %d", desc->abi_version, SMPC_ABI_VERSION);
+    if (desc->nq < 5 || desc->nq > SMPC_MAX_NQ) return fail(nullptr, SMPC_EINVAL, "nq=%d unsupported", desc->nq);
+    if (desc->N < 1 || desc->N > SMPC_MAX_N) return fail(nullptr, SMPC_EINVAL, "N=%d outside 1..%d", desc->N, SMPC_MAX_N);
+    if (desc->n_rows < 0 || desc->n_rows > SMPC_MAX_ROWS || desc->n_points < 1 || desc->n_points > SMPC_MAX_POINTS)
+        return fail(nullptr, SMPC_EINVAL, "n_rows / n_points out of range");
+    for (int i = 0; i < desc->n_points; i++)
+        if (desc->points[i].link >= desc->nq) return fail(nullptr, SMPC_EINVAL, "point %d rides on link %d >= nq", i, desc->points[i].link);
+    for (int r = 0; r < desc->n_rows; r++) {
+        const smpc_row& row = desc->rows[r];
+        if (row.kind < 0 || row.kind > SMPC_ROW_COORD || row.pa < 0 || row.pa >= desc->n_points)
+            return fail(nullptr, SMPC_EINVAL, "row %d malformed", r);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SMPC_EHIP, "no HIP device visible: the engine has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, SMPC_EINVAL, "device %d of %d", device, ndev);
+    smpc_handle* h = new (std::nothrow) smpc_handle();
+    if (!h) return fail(nullptr, SMPC_ENOMEM, "out of host memory");
+    h->desc = *desc;
+    h->device = device;
+    h->N = desc->N;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_desc, sizeof(smpc_problem_desc));
+    if (e == hipSuccess) e = hipMemcpy(h->d_desc, desc, sizeof(smpc_problem_desc), hipMemcpyHostToDevice);
+    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&h->ev_t[i]);
+    if (e != hipSuccess) {
+        fail(nullptr, SMPC_EHIP, "device setup failed: %s", hipGetErrorString(e));
+        smpc_destroy(h);
+        return SMPC_EHIP;
+    }
+    int rc = upload_bounds(h, nullptr, nullptr);
+    if (rc) {
+        snprintf(g_create_err, sizeof(g_create_err), "%s", h->err);
+        smpc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SMPC_OK;
+}
+
+void smpc_destroy(smpc_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->d_desc, h->d_lo, h->d_hi, h->d_ev, h->d_ws, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
+                    h->d_st, h->d_it, h->d_S, h->d_y, h->d_GS, h->d_dA, h->d_dB, h->d_tmp};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int l = 0; l < SMPC_MAX_LAYERS; l++) {
+        if (h->d_Wfwd[l]) (void)hipFree(h->d_Wfwd[l]);
+        if (h->d_Wbwd[l]) (void)hipFree(h->d_Wbwd[l]);
+        if (h->d_bias[l]) (void)hipFree(h->d_bias[l]);
+        if (h->d_act[l]) (void)hipFree(h->d_act[l]);
+        if (h->d_dg[l]) (void)hipFree(h->d_dg[l]);
+    }
+    for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int smpc_set_mlp(smpc_handle* h, int nlayers, const int32_t* dims, const float* const* W, const float* const* b,
+                 int on_device) {
+    if (!h || !dims || !W || !b) return fail(h, SMPC_EINVAL, "null argument");
+    if (nlayers < 2 || nlayers > SMPC_MAX_LAYERS) return fail(h, SMPC_EINVAL, "nlayers=%d outside 2..%d", nlayers, SMPC_MAX_LAYERS);
+    const int in = dims[0], H = dims[1];
+    if (in != 2 * h->desc.nn_dof || in > MLP_KPAD) return fail(h, SMPC_EINVAL, "input width %d != 2*n_dof_safe_set", in);
+    if (H % 64 != 0 || dims[nlayers] != 1) return fail(h, SMPC_EINVAL, "hidden width must be a multiple of 64 and output 1");
+    for (int l = 1; l < nlayers; l++)
+        if (dims[l] != H) return fail(h, SMPC_EINVAL, "hidden layers must share one width");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->capM = 0;
+    for (int l = 0; l < nlayers; l++) {
+        const int ni = dims[l], no = dims[l + 1];
+        std::vector<float> w((size_t)ni * no), bb(no);
+        HIPCHK(h, hipMemcpy(w.data(), W[l], w.size() * sizeof(float), on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        HIPCHK(h, hipMemcpy(bb.data(), b[l], bb.size() * sizeof(float), on_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        const int kf = l == 0 ? MLP_KPAD : ni;            // rows of the forward operand W^T
+        const int nb = l == 0 ? MLP_NPAD : ni;            // columns of the backward operand W
+        std::vector<float> wf((size_t)kf * no, 0.0f), wb((size_t)no * nb, 0.0f);
+        for (int o = 0; o < no; o++)
+            for (int i = 0; i < ni; i++) {
+                wf[(size_t)i * no + o] = w[(size_t)o * ni + i];
+                wb[(size_t)o * nb + i] = w[(size_t)o * ni + i];
+            }
+        int rc;
+        if ((rc = dev_alloc(h, &h->d_Wfwd[l], wf.size()))) return rc;
+        if ((rc = dev_alloc(h, &h->d_Wbwd[l], wb.size()))) return rc;
+        if ((rc = dev_alloc(h, &h->d_bias[l], bb.size()))) return rc;
+        HIPCHK(h, hipMemcpy(h->d_Wfwd[l], wf.data(), wf.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->d_Wbwd[l], wb.data(), wb.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->d_bias[l], bb.data(), bb.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    h->nlayers = nlayers;
+    for (int l = 0; l <= nlayers; l++) h->dims[l] = dims[l];
+    h->H = H;
+    return SMPC_OK;
+}
+
+int smpc_set_horizon(smpc_handle* h, int N) {
+    if (!h) return SMPC_EINVAL;
+    if (N < 1 || N > SMPC_MAX_N) return fail(h, SMPC_EINVAL, "N=%d outside 1..%d", N, SMPC_MAX_N);
+    (void)hipSetDevice(h->device);
+    h->N = N;
+    h->ws_bytes = 0;  // workspace layout depends on N
+    return upload_bounds(h, nullptr, nullptr);
+}
+
+int smpc_set_stage_bounds(smpc_handle* h, const double* lo, const double* hi) {
+    if (!h) return SMPC_EINVAL;
+    if ((lo == nullptr) != (hi == nullptr)) return fail(h, SMPC_EINVAL, "lo and hi must both be given or both be NULL");
+    (void)hipSetDevice(h->device);
+    return upload_bounds(h, lo, hi);
+}
+
+int smpc_solve_batch(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
+                     double* x_out, double* u_out, int32_t* status, int32_t* qp_iter, int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !x0 || !xg || !ug || !p || !x_out || !u_out || !status) return fail(h, SMPC_EINVAL, "bad argument");
+    (void)hipSetDevice(h->device);
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    const int N = h->N, nx = 2 * h->desc.nq, nu = h->desc.nq;
+    if (on_device) {
+        DISPATCH_NQ(h, (launch_solve<NQ_>(h, B, x0, xg, ug, p, x_out, u_out, status, qp_iter)));
+        return rc;
+    }
+    if ((rc = ensure_io(h, B))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_x0, x0, sizeof(double) * B * nx, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_xg, xg, sizeof(double) * B * (N + 1) * nx, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_ug, ug, sizeof(double) * B * N * nu, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_p, p, sizeof(double) * B * (N + 1) * SMPC_NP, hipMemcpyHostToDevice, s));
+    DISPATCH_NQ(h, (launch_solve<NQ_>(h, B, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo, h->d_st, h->d_it)));
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(x_out, h->d_xo, sizeof(double) * B * (N + 1) * nx, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(u_out, h->d_uo, sizeof(double) * B * N * nu, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(status, h->d_st, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    if (qp_iter) HIPCHK(h, hipMemcpyAsync(qp_iter, h->d_it, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return SMPC_OK;
+}
+
+int smpc_eval_nodes(smpc_handle* h, int B, const double* xg, const double* ug, const double* p, smpc_node_eval* out,
+                    int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !xg || !ug || !p || !out) return fail(h, SMPC_EINVAL, "bad argument");
+    (void)hipSetDevice(h->device);
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    const int N = h->N, nx = 2 * h->desc.nq, nu = h->desc.nq;
+    if (on_device) {
+        DISPATCH_NQ(h, (launch_eval<NQ_>(h, B, xg, ug, p, out)));
+        return rc;
+    }
+    if ((rc = ensure_io(h, B))) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_xg, xg, sizeof(double) * B * (N + 1) * nx, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_ug, ug, sizeof(double) * B * N * nu, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_p, p, sizeof(double) * B * (N + 1) * SMPC_NP, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemsetAsync(h->d_ev, 0, sizeof(smpc_node_eval) * (size_t)B * (N + 1), s));
+    DISPATCH_NQ(h, (launch_eval<NQ_>(h, B, h->d_xg, h->d_ug, h->d_p, h->d_ev)));
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_ev, sizeof(smpc_node_eval) * (size_t)B * (N + 1), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return SMPC_OK;
+}
+
+int smpc_guess_correction(smpc_handle* h, int B, double* xg, const double* ug, int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !xg || !ug) return fail(h, SMPC_EINVAL, "bad argument");
+    (void)hipSetDevice(h->device);
+    const int N = h->N, nq = h->desc.nq, nx = 2 * nq;
+    hipStream_t s = h->stream;
+    double *dx = xg;
+    const double* du = ug;
+    if (!on_device) {
+        int rc;
+        if ((rc = ensure_tmp(h, sizeof(double) * B * ((size_t)(N + 1) * nx + (size_t)N * nq)))) return rc;
+        dx = (double*)h->d_tmp;
+        double* duw = dx + (size_t)B * (N + 1) * nx;
+        HIPCHK(h, hipMemcpyAsync(dx, xg, sizeof(double) * B * (N + 1) * nx, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(duw, ug, sizeof(double) * B * N * nq, hipMemcpyHostToDevice, s));
+        du = duw;
+    }
+    hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 255) / 256), dim3(256), 0, s, B, N, nq, h->desc.dt, dx, du);
+    HIPCHK(h, hipGetLastError());
+    if (!on_device) {
+        HIPCHK(h, hipMemcpyAsync(xg, dx, sizeof(double) * B * (N + 1) * nx, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    return SMPC_OK;
+}
+
+int smpc_provide_control(smpc_handle* h, int B, const int32_t* accept, const double* x_temp, const double* u_temp,
+                         double* xg, double* ug, double* u_apply, int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !accept || !x_temp || !u_temp || !xg || !ug || !u_apply) return fail(h, SMPC_EINVAL, "bad argument");
+    (void)hipSetDevice(h->device);
+    const int N = h->N, nq = h->desc.nq, nx = 2 * nq;
+    hipStream_t s = h->stream;
+    const size_t nX = (size_t)B * (N + 1) * nx, nU = (size_t)B * N * nq;
+    if (on_device) {
+        hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, accept, x_temp,
+                           u_temp, xg, ug, u_apply);
+        HIPCHK(h, hipGetLastError());
+        return SMPC_OK;
+    }
+    int rc;
+    if ((rc = ensure_tmp(h, sizeof(double) * (2 * nX + 2 * nU + (size_t)B * nq) + sizeof(int32_t) * B + 64))) return rc;
+    double* d_xt = (double*)h->d_tmp;
+    double* d_ut = d_xt + nX;
+    double* d_xg = d_ut + nU;
+    double* d_ug = d_xg + nX;
+    double* d_ua = d_ug + nU;
+    int32_t* d_acc = (int32_t*)(d_ua + (size_t)B * nq);
+    HIPCHK(h, hipMemcpyAsync(d_xt, x_temp, sizeof(double) * nX, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_ut, u_temp, sizeof(double) * nU, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_xg, xg, sizeof(double) * nX, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_ug, ug, sizeof(double) * nU, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_acc, accept, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, d_acc, d_xt, d_ut,
+                       d_xg, d_ug, d_ua);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(xg, d_xg, sizeof(double) * nX, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(ug, d_ug, sizeof(double) * nU, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(u_apply, d_ua, sizeof(double) * B * nq, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return SMPC_OK;
+}
+
+int smpc_check_trajectory(smpc_handle* h, int B, int n_nodes, const double* x, const double* x_min, const double* x_max,
+                          double tol_x, const double* row_lb_chk, const double* row_ub_chk, double alpha, double tol_safe,
+                          int32_t* state_ok, int32_t* nn_ok, int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || n_nodes <= 0 || !x || !x_min || !x_max || !state_ok) return fail(h, SMPC_EINVAL, "bad argument");
+    if (h->desc.n_rows > 0 && (!row_lb_chk || !row_ub_chk)) return fail(h, SMPC_EINVAL, "row check bounds missing");
+    if (nn_ok && h->nlayers == 0) return fail(h, SMPC_ESTATE, "nn_ok requested but smpc_set_mlp was not called");
+    (void)hipSetDevice(h->device);
+    const int nq = h->desc.nq, nx = 2 * nq, nr = h->desc.n_rows;
+    hipStream_t s = h->stream;
+    const size_t M = (size_t)B * n_nodes;
+    // bounds always come from the host side of the caller: small, copied into scratch
+    int rc;
+    const size_t small = sizeof(double) * (2 * nx + 2 * SMPC_MAX_ROWS);
+    const size_t big = on_device ? 0 : sizeof(double) * M * nx + sizeof(int32_t) * (B + M) + 64;
+    if ((rc = ensure_tmp(h, small + big))) return rc;
+    double* d_min = (double*)h->d_tmp;
+    double* d_max = d_min + nx;
+    double* d_rlb = d_max + nx;
+    double* d_rub = d_rlb + SMPC_MAX_ROWS;
+    hipMemcpyKind kind = on_device ? hipMemcpyDefault : hipMemcpyHostToDevice;
+    HIPCHK(h, hipMemcpyAsync(d_min, x_min, sizeof(double) * nx, kind, s));
+    HIPCHK(h, hipMemcpyAsync(d_max, x_max, sizeof(double) * nx, kind, s));
+    if (nr > 0) {
+        HIPCHK(h, hipMemcpyAsync(d_rlb, row_lb_chk, sizeof(double) * nr, kind, s));
+        HIPCHK(h, hipMemcpyAsync(d_rub, row_ub_chk, sizeof(double) * nr, kind, s));
+    }
+    const double* d_x = x;
+    int32_t *d_ok = state_ok, *d_nn = nn_ok;
+    if (!on_device) {
+        double* dx = d_rub + SMPC_MAX_ROWS;
+        HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * M * nx, hipMemcpyHostToDevice, s));
+        d_x = dx;
+        d_ok = (int32_t*)(dx + M * nx);
+        d_nn = d_ok + B;
+    }
+    std::vector<int32_t> ones(B, 1);
+    HIPCHK(h, hipMemcpyAsync(d_ok, ones.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));  // `ones` is a stack-lifetime source
+    switch (nq) {
+    case 5: hipLaunchKernelGGL((k_check_nodes<5>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
+    case 6: hipLaunchKernelGGL((k_check_nodes<6>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
+    default: hipLaunchKernelGGL((k_check_nodes<7>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
+    }
+    HIPCHK(h, hipGetLastError());
+    if (nn_ok) {
+        DISPATCH_NQ(h, (run_mlp<NQ_>(h, (int)M, 0, 0, d_x, false)));
+        if (rc) return rc;
+        switch (nq) {
+        case 5: hipLaunchKernelGGL((k_check_nn<5>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
+        case 6: hipLaunchKernelGGL((k_check_nn<6>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
+        default: hipLaunchKernelGGL((k_check_nn<7>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    if (!on_device) {
+        HIPCHK(h, hipMemcpyAsync(state_ok, d_ok, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
+        if (nn_ok) HIPCHK(h, hipMemcpyAsync(nn_ok, d_nn, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    return SMPC_OK;
+}
+
+int smpc_plant_step(smpc_handle* h, int B, const double* x, const double* u, const smpc_joint* joints_noisy,
+                    const double* tau_noise, double* x_next, double* u_eff, int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !x || !u || !x_next) return fail(h, SMPC_EINVAL, "bad argument");
+    (void)hipSetDevice(h->device);
+    const int nq = h->desc.nq, nx = 2 * nq;
+    hipStream_t s = h->stream;
+    const double *dx = x, *du = u, *dn = tau_noise;
+    const smpc_joint* dj = joints_noisy;
+    double *dxn = x_next, *due = u_eff;
+    if (!on_device) {
+        int rc;
+        const size_t bytes = sizeof(double) * B * (2 * (size_t)nx + 3 * (size_t)nq) + sizeof(smpc_joint) * (size_t)B * nq + 64;
+        if ((rc = ensure_tmp(h, bytes))) return rc;
+        double* w = (double*)h->d_tmp;
+        double* wx = w; w += (size_t)B * nx;
+        double* wu = w; w += (size_t)B * nq;
+        double* wn = w; w += (size_t)B * nq;
+        dxn = w; w += (size_t)B * nx;
+        due = w; w += (size_t)B * nq;
+        smpc_joint* wj = (smpc_joint*)w;
+        HIPCHK(h, hipMemcpyAsync(wx, x, sizeof(double) * B * nx, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(wu, u, sizeof(double) * B * nq, hipMemcpyHostToDevice, s));
+        dx = wx; du = wu;
+        if (tau_noise) { HIPCHK(h, hipMemcpyAsync(wn, tau_noise, sizeof(double) * B * nq, hipMemcpyHostToDevice, s)); dn = wn; }
+        if (joints_noisy) { HIPCHK(h, hipMemcpyAsync(wj, joints_noisy, sizeof(smpc_joint) * (size_t)B * nq, hipMemcpyHostToDevice, s)); dj = wj; }
+    }
+    switch (nq) {
+    case 5: hipLaunchKernelGGL((k_plant_step<5>), dim3((B + 63) / 64), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
+    case 6: hipLaunchKernelGGL((k_plant_step<6>), dim3((B + 63) / 64), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
+    default: hipLaunchKernelGGL((k_plant_step<7>), dim3((B + 63) / 64), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
+    }
+    HIPCHK(h, hipGetLastError());
+    if (!on_device) {
+        HIPCHK(h, hipMemcpyAsync(x_next, dxn, sizeof(double) * B * nx, hipMemcpyDeviceToHost, s));
+        if (u_eff) HIPCHK(h, hipMemcpyAsync(u_eff, due, sizeof(double) * B * nq, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    return SMPC_OK;
+}
+
+int smpc_sync(smpc_handle* h) {
+    if (!h) return SMPC_EINVAL;
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SMPC_OK;
+}
+
+void* smpc_stream(smpc_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int smpc_enable_timing(smpc_handle* h, int on) {
+    if (!h) return SMPC_EINVAL;
+    h->timing = on ? 1 : 0;
+    return SMPC_OK;
+}
+
+int smpc_get_timing(smpc_handle* h, float* ms4) {
+    if (!h || !ms4) return SMPC_EINVAL;
+    if (!h->timing) return fail(h, SMPC_ESTATE, "timing not enabled");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
+    HIPCHK(h, hipEventElapsedTime(&ms4[0], h->ev_t[0], h->ev_t[1]));
+    HIPCHK(h, hipEventElapsedTime(&ms4[1], h->ev_t[1], h->ev_t[2]));
+    HIPCHK(h, hipEventElapsedTime(&ms4[2], h->ev_t[2], h->ev_t[3]));
+    HIPCHK(h, hipEventElapsedTime(&ms4[3], h->ev_t[0], h->ev_t[3]));
+    return SMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// kernels_callers.hpp -- the callers on either side of the solve: warm-start
+// roll-out and shift, feasibility predicates, plant step.  All embarrassingly parallel over instances.
+#pragma once
+#include "device_model.hpp"
+
+namespace smpc {
+
+// guessCorrection (controller.py:226-231): one thread per (instance, joint), sequential in k
+__global__ void k_guess_correction(int B, int N, int nq, double dt, double* __restrict__ xg,
+                                   const double* __restrict__ ug) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * nq) return;
+    const long b = t / nq;
+    const int i = (int)(t % nq);
+    const int nx = 2 * nq;
+    double* x = xg + b * (N + 1) * nx;
+    const double* u = ug + b * N * nq;
+    double q = x[i], v = x[nq + i];
+    const double c = 0.5 * dt * dt;
+    for (int k = 0; k < N; k++) {
+        const double uk = u[k * nq + i];
+        q = q + dt * v + c * uk;
+        v = v + dt * uk;
+        x[(k + 1) * nx + i] = q;
+        x[(k + 1) * nx + nq + i] = v;
+    }
+}
+
+// provideControl (controller.py:169-184): one thread per (instance, column of x or u)
+__global__ void k_provide_control(int B, int N, int nq, const int32_t* __restrict__ accept,
+                                  const double* __restrict__ xt, const double* __restrict__ ut,
+                                  double* __restrict__ xg, double* __restrict__ ug, double* __restrict__ u_apply) {
+    const int nx = 2 * nq, ncol = nx + nq;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * ncol) return;
+    const long b = t / ncol;
+    const int c = (int)(t % ncol);
+    const bool acc = accept[b] != 0;
+    if (c < nx) {
+        double* x = xg + b * (N + 1) * nx;
+        const double* src = acc ? xt + b * (N + 1) * nx : x;
+        for (int k = 0; k < N; k++) x[k * nx + c] = src[(k + 1) * nx + c];
+        x[N * nx + c] = x[(N - 1) * nx + c];
+    } else {
+        const int i = c - nx;
+        double* u = ug + b * N * nq;
+        const double* src = acc ? ut + b * N * nq : u;
+        u_apply[b * nq + i] = src[i];
+        for (int k = 0; k + 1 < N; k++) u[k * nq + i] = src[(k + 1) * nq + i];
+        if (N > 1) u[(N - 1) * nq + i] = u[(N - 2) * nq + i];
+        else u[i] = src[i];
+    }
+}
+
+// checkStateConstraints over trajectories (env_model.py:170-173, 236-243): bounds with tolerance + collision rows within
+// the check bounds.  One thread per (instance, node); instance verdicts are AND-ed with an atomic.
+template <int NQ>
+__global__ void k_check_nodes(const smpc_problem_desc* __restrict__ D, int B, int n_nodes, const double* __restrict__ x,
+                              const double* __restrict__ x_min, const double* __restrict__ x_max, double tol_x,
+                              const double* __restrict__ row_lb, const double* __restrict__ row_ub,
+                              int32_t* __restrict__ state_ok) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * n_nodes) return;
+    constexpr int NX = 2 * NQ;
+    const double* xk = x + t * NX;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < NX; i++) ok = ok && (xk[i] >= x_min[i] - tol_x) && (xk[i] <= x_max[i] + tol_x);
+    double q[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) q[i] = xk[i];
+    Mat3<double> Rw[NQ];
+    Vec3<double> pw[NQ], zw[NQ];
+    fk_world<NQ>(D->joints, q, Rw, pw, zw);
+    for (int r = 0; r < D->n_rows; r++) {
+        const smpc_row& row = D->rows[r];
+        double v;
+        switch (row.kind) {
+        case SMPC_ROW_SEG_FIXEDSEG:
+            v = segment_dist2<NQ>(point_with_jacobian<NQ>(D->points[row.pa], Rw, pw, zw),
+                                  point_with_jacobian<NQ>(D->points[row.pb], Rw, pw, zw), dv_const<NQ>(row.C),
+                                  dv_const<NQ>(row.D)).v;
+            break;
+        case SMPC_ROW_SEG_SEG:
+            v = segment_dist2<NQ>(point_with_jacobian<NQ>(D->points[row.pa], Rw, pw, zw),
+                                  point_with_jacobian<NQ>(D->points[row.pb], Rw, pw, zw),
+                                  point_with_jacobian<NQ>(D->points[row.pc], Rw, pw, zw),
+                                  point_with_jacobian<NQ>(D->points[row.pd], Rw, pw, zw)).v;
+            break;
+        case SMPC_ROW_SEG_POINT:
+            v = ball_segment_dist2<NQ>(point_with_jacobian<NQ>(D->points[row.pa], Rw, pw, zw),
+                                       point_with_jacobian<NQ>(D->points[row.pb], Rw, pw, zw), row.len2,
+                                       dv_const<NQ>(row.C)).v;
+            break;
+        case SMPC_ROW_POINT_POINT: {
+            DV3<NQ> w = point_with_jacobian<NQ>(D->points[row.pa], Rw, pw, zw) - dv_const<NQ>(row.C);
+            v = dot(w, w).v;
+            break;
+        }
+        default: {
+            DV3<NQ> P = point_with_jacobian<NQ>(D->points[row.pa], Rw, pw, zw);
+            v = (row.axis == 0 ? P.x.v : (row.axis == 1 ? P.y.v : P.z.v)) - row.offset;
+            break;
+        }
+        }
+        ok = ok && (row_lb[r] <= v) && (v <= row_ub[r]);
+    }
+    if (!ok) atomicAnd(&state_ok[t / n_nodes], 0);
+}
+
+// safe-set acceptance test (safe_set.py:61-68): g(x, alpha) within [-tol, 1e6 + tol]
+template <int NQ>
+__global__ void k_check_nn(const smpc_problem_desc* __restrict__ D, int M, const double* __restrict__ x, double alpha,
+                           double tol_safe, const float* __restrict__ y, int32_t* __restrict__ nn_ok) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const double* xk = x + (size_t)m * 2 * NQ;
+    const int nd = D->nn_dof;
+    double vn2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const double v = i < nd ? xk[NQ + i] + (i == 0 ? D->nn_eps : 0.0) : 0.0;
+        vn2 += v * v;
+    }
+    const double g = (double)y[m] * (100.0 - alpha) / 100.0 - sqrt(vn2);
+    nn_ok[m] = (g >= -tol_safe) && (g <= 1e6 + tol_safe);
+}
+
+// plant step AdamModel.integrate (env_model.py:192-206); one thread per instance
+template <int NQ>
+__global__ __launch_bounds__(64) void k_plant_step(const smpc_problem_desc* __restrict__ D, int B, const double* __restrict__ x,
+                             const double* __restrict__ u, const smpc_joint* __restrict__ joints_noisy,
+                             const double* __restrict__ tau_noise, double* __restrict__ x_next,
+                             double* __restrict__ u_eff) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    constexpr int NX = 2 * NQ;
+    const smpc_joint* J = joints_noisy ? joints_noisy + (size_t)b * NQ : D->joints;
+    const double* xb = x + (size_t)b * NX;
+    double q[NQ], qd[NQ], uu[NQ], zero[NQ], tau[NQ], h[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) { q[i] = xb[i]; qd[i] = xb[NQ + i]; uu[i] = u[(size_t)b * NQ + i]; zero[i] = 0.0; }
+    rnea_world<NQ, double>(J, D->gravity, q, qd, uu, tau);
+    rnea_world<NQ, double>(J, D->gravity, q, qd, zero, h);
+    double M[NQ][NQ];
+    const double g0[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+        double e[NQ], col[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; i++) e[i] = (i == j) ? 1.0 : 0.0;
+        rnea_world<NQ, double>(J, g0, q, zero, e, col);
+#pragma unroll
+        for (int i = 0; i < NQ; i++) M[i][j] = col[i];
+    }
+    double rhs[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        double t = tau[i] + (tau_noise ? tau_noise[(size_t)b * NQ + i] : 0.0);
+        const double tm = J[i].tau_max;
+        t = fmin(fmax(t, -tm), tm);
+        rhs[i] = t - h[i];
+    }
+    // M is symmetric positive definite: Cholesky solve
+    double L[NQ][NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) {
+        double d = M[j][j];
+#pragma unroll
+        for (int t = 0; t < j; t++) d = fma(-L[j][t], L[j][t], d);
+        const double lj = sqrt(d);
+        L[j][j] = lj;
+#pragma unroll
+        for (int i = j + 1; i < NQ; i++) {
+            double v = 0.5 * (M[i][j] + M[j][i]);
+#pragma unroll
+            for (int t = 0; t < j; t++) v = fma(-L[i][t], L[j][t], v);
+            L[i][j] = v / lj;
+        }
+    }
+    double y[NQ], acc[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        double v = rhs[i];
+#pragma unroll
+        for (int t = 0; t < i; t++) v = fma(-L[i][t], y[t], v);
+        y[i] = v / L[i][i];
+    }
+#pragma unroll
+    for (int i = NQ - 1; i >= 0; i--) {
+        double v = y[i];
+#pragma unroll
+        for (int t = i + 1; t < NQ; t++) v = fma(-L[t][i], acc[t], v);
+        acc[i] = v / L[i][i];
+    }
+    const double dt = D->dt, c = 0.5 * dt * dt;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        x_next[(size_t)b * NX + i] = q[i] + dt * qd[i] + c * acc[i];
+        x_next[(size_t)b * NX + NQ + i] = qd[i] + dt * acc[i];
+        if (u_eff) u_eff[(size_t)b * NQ + i] = acc[i];
+    }
+}
+
+}  // namespace smpc

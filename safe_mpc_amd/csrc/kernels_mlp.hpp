@@ -1,0 +1,177 @@
+// kernels_mlp.hpp -- the learned safe-set row: batched MLP forward + input-gradient on the matrix cores.
+//
+// Replaces l4casadi + libtorch (reference src/safe_mpc/safe_set.py:89-94, N3 in SURVEY section 2), which evaluates the
+// network one sample at a time on the CPU.  Here all (instance, node) pairs that carry the row are gathered into one
+// [M x in] matrix and pushed through  in -> H -> H -> ... -> 1  as dense GEMMs.  The reference's torch model is fp32
+// (safe_set.py:75-78), so the GEMMs use the exact-fp32 MFMA  v_mfma_f32_32x32x2_f32  (a k-ordered fmaf chain, no
+// reduced-precision path): one wave owns a 32 x 64 tile of C, operands come straight from L2-resident global memory
+// (A: one dwordx4 per lane per 8-deep K chunk, B: eight coalesced dword rows), no LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_model.hpp"
+
+namespace smpc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MLP_KPAD = 16;   // padded input width (2*nn_dof <= 14)
+constexpr int MLP_NPAD = 64;   // padded width of the last backward GEMM (tile width)
+
+__device__ __forceinline__ float gelu_tanh_f(float a, float* dg) {
+    // GELU(approximate='tanh') (parser.py:99) and its derivative, fp32
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    const float a2 = a * a;
+    const float inner = k0 * (a + k1 * a * a2);
+    const float th = tanhf(inner);
+    *dg = 0.5f * (1.0f + th) + 0.5f * a * (1.0f - th * th) * k0 * (1.0f + 3.0f * k1 * a2);
+    return 0.5f * a * (1.0f + th);
+}
+
+enum { EPI_BIAS_GELU = 0, EPI_MUL = 1, EPI_PLAIN = 2 };
+
+// C[M x N] = A[M x K] * Bm[K x N]  (row-major, M % 32 == 0, N % 64 == 0, K % 8 == 0)
+//   EPI_BIAS_GELU: out1 = gelu(acc + bias[n]), out2 = gelu'(acc + bias[n])
+//   EPI_MUL:       out1 = acc * aux[m][n]
+//   EPI_PLAIN:     out1 = acc
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const float* __restrict__ A,
+                                                  const float* __restrict__ Bm, const float* __restrict__ bias,
+                                                  const float* __restrict__ aux, float* __restrict__ out1,
+                                                  float* __restrict__ out2) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    const int n0 = blockIdx.y * 64;
+    if (m0 >= M) return;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+    const float* arow = A + (size_t)(m0 + li) * K + 4 * lh;
+    const float* bcol = Bm + (size_t)(4 * lh) * N + n0 + li;
+    for (int kc = 0; kc < K; kc += 8) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kc);
+        float b0[4], b1[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            b0[r] = bcol[(size_t)(kc + r) * N];
+            b1[r] = bcol[(size_t)(kc + r) * N + 32];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], b0[r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], b1[r], acc1, 0, 0, 0);
+        }
+    }
+    // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        const int row = m0 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int col = n0 + 32 * half + li;
+            const float a = half ? acc1[reg] : acc0[reg];
+            const size_t o = (size_t)row * N + col;
+            if (EPI == EPI_BIAS_GELU) {
+                float dg;
+                out1[o] = gelu_tanh_f(a + bias[col], &dg);
+                out2[o] = dg;
+            } else if (EPI == EPI_MUL) {
+                out1[o] = a * aux[o];
+            } else {
+                out1[o] = a;
+            }
+        }
+    }
+}
+
+// features of the safe-set network (safe_set.py:82-87): s = [(q - mean)/std ; v/|v|], v = qd with eps on v_0.
+// row m <-> node:  mode 0: node = m (plain list of states);  mode 1 (terminal): node = m (N+1) + N;
+//                  mode 2 (all nodes but the first): b = m / N, k = 1 + m % N.
+__device__ __forceinline__ long nn_row_to_node(int mode, int N, int m) {
+    if (mode == 0) return m;
+    if (mode == 1) return (long)m * (N + 1) + N;
+    return (long)(m / N) * (N + 1) + 1 + m % N;
+}
+template <int NQ>
+__global__ void k_nn_features(const smpc_problem_desc* __restrict__ D, int M, int Mpad, int N, int mode,
+                              const double* __restrict__ xg, float* __restrict__ S) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= Mpad) return;
+    float* s = S + (size_t)m * MLP_KPAD;
+#pragma unroll
+    for (int i = 0; i < MLP_KPAD; i++) s[i] = 0.0f;
+    if (m >= M) return;
+    const double* x = xg + nn_row_to_node(mode, N, m) * (2 * NQ);
+    const int nd = D->nn_dof;
+    double v[NQ], vn2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        v[i] = i < nd ? x[NQ + i] + (i == 0 ? D->nn_eps : 0.0) : 0.0;
+        vn2 += v[i] * v[i];
+    }
+    const double inv = 1.0 / sqrt(vn2);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        if (i < nd) {
+            s[i] = (float)((x[i] - D->nn_mean[i]) / D->nn_std[i]);
+            s[nd + i] = (float)(v[i] * inv);
+        }
+    }
+}
+
+// output layer y = a . w + b  and  delta = w (.) gelu'(z) of the last hidden layer; one wave per row
+__global__ __launch_bounds__(256) void k_nn_output(int M, int H, const float* __restrict__ A, const float* __restrict__ Dg,
+                                                   const float* __restrict__ w, const float* __restrict__ bias,
+                                                   float* __restrict__ y, float* __restrict__ delta) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float acc = 0.0f;
+    for (int c = lane; c < H; c += 64) {
+        const size_t o = (size_t)row * H + c;
+        acc = fmaf(A[o], w[c], acc);
+        delta[o] = w[c] * Dg[o];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[row] = acc + bias[0];
+}
+
+// chain rule back to the state (safe_set.py:82-94) and the per-node switch (utils.py:207-210): writes nn_val, nn_grad
+template <int NQ>
+__global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N, int mode,
+                           const double* __restrict__ xg, const double* __restrict__ p, const float* __restrict__ y,
+                           const float* __restrict__ GS, smpc_node_eval* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const long node = nn_row_to_node(mode, N, m);
+    const double* x = xg + node * (2 * NQ);
+    const double* pk = p + node * SMPC_NP;
+    smpc_node_eval* o = out + node;
+    if (!(pk[4] > 0.0)) return;  // switched off: row sits mid-bounds, leave (0, 0)
+    const int nd = D->nn_dof;
+    const float* gs = GS + (size_t)m * MLP_NPAD;
+    double v[NQ], vn2 = 0.0, gdv = 0.0;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        v[i] = i < nd ? x[NQ + i] + (i == 0 ? D->nn_eps : 0.0) : 0.0;
+        vn2 += v[i] * v[i];
+    }
+    const double vn = sqrt(vn2);
+#pragma unroll
+    for (int i = 0; i < NQ; i++)
+        if (i < nd) gdv += (double)gs[nd + i] * v[i];
+    const double kap = (100.0 - pk[3]) / 100.0;
+    o->nn_val = (double)y[m] * kap - vn;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        if (i < nd) {
+            o->nn_grad[i] = kap * (double)gs[i] / D->nn_std[i];
+            o->nn_grad[NQ + i] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
+        }
+    }
+}
+
+}  // namespace smpc

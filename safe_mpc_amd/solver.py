@@ -1,0 +1,234 @@
+"""``BatchedOcpSolver``: Python face of the HIP engine (include/smpc.h) -- what ``self.ocp_solver`` is in the reference
+(an ``acados_template.AcadosOcpSolver``, controller.py:247), but for B instances per call.
+
+Inputs may be numpy arrays (host path: copied in and out by the engine, synchronous) or ROCm torch tensors
+(device path: the engine only gets ``data_ptr()``s and enqueues on its own stream; call :meth:`sync`).
+PyTorch is used for device memory only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .problem import JOINT_DTYPE, NODE_EVAL_DTYPE, OcpProblem
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith('torch')
+
+
+class BatchedOcpSolver:
+    def __init__(self, problem: OcpProblem, net=None, device=0):
+        self.problem = problem
+        self.L = _lib.lib()
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self.L.smpc_create(C.byref(problem.desc), self.device, C.byref(h))
+        if rc != 0:
+            raise _lib.EngineError(f'smpc_create failed ({rc}): {self.L.smpc_last_error(None).decode()}')
+        self.h = h
+        self.nq, self.nx, self.nu = problem.nq, problem.nx, problem.nu
+        self.N = problem.N
+        self.net = None
+        if net is not None:
+            self.set_mlp(net)
+
+    # -- lifetime ------------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.smpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise _lib.EngineError(f'engine error {rc}: {self.L.smpc_last_error(self.h).decode()}')
+
+    def set_mlp(self, net):
+        """net: SafeSetNet (weights as numpy fp32) -- or anything with .weights/.biases lists of [out, in] / [out]."""
+        Ws = [np.ascontiguousarray(w, np.float32) for w in net.weights]
+        bs = [np.ascontiguousarray(b, np.float32) for b in net.biases]
+        n = len(Ws)
+        dims = np.array([Ws[0].shape[1]] + [w.shape[0] for w in Ws], np.int32)
+        Wp = (C.c_void_p * n)(*[w.ctypes.data for w in Ws])
+        bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
+        self._chk(self.L.smpc_set_mlp(self.h, n, dims.ctypes.data_as(C.POINTER(C.c_int32)), Wp, bp, 0))
+        self.net = net
+
+    def set_horizon(self, N):
+        self._chk(self.L.smpc_set_horizon(self.h, int(N)))
+        self.N = int(N)
+
+    def set_stage_bounds(self, lo=None, hi=None):
+        if lo is None:
+            self._chk(self.L.smpc_set_stage_bounds(self.h, None, None))
+            return
+        lo = np.ascontiguousarray(lo, np.float64)
+        hi = np.ascontiguousarray(hi, np.float64)
+        assert lo.shape == (self.N + 1, self.nx) and hi.shape == lo.shape
+        self._chk(self.L.smpc_set_stage_bounds(self.h, lo.ctypes.data, hi.ctypes.data))
+
+    def sync(self):
+        self._chk(self.L.smpc_sync(self.h))
+
+    def enable_timing(self, on=True):
+        self._chk(self.L.smpc_enable_timing(self.h, int(on)))
+
+    def timing(self):
+        ms = (C.c_float * 4)()
+        self._chk(self.L.smpc_get_timing(self.h, ms))
+        return {'time_lin': ms[0] * 1e-3, 'time_nn': ms[1] * 1e-3, 'time_qp': ms[2] * 1e-3, 'time_tot': ms[3] * 1e-3}
+
+    # -- argument plumbing -----------------------------------------------------------------------------------------------
+    def _prep(self, arrs, shapes, dtypes=None):
+        """returns (pointers, on_device, keepalive)"""
+        dev = _is_torch(arrs[0])
+        ptrs, keep = [], []
+        for i, (a, shp) in enumerate(zip(arrs, shapes)):
+            if a is None:
+                ptrs.append(None)
+                continue
+            if _is_torch(a) != dev:
+                raise TypeError('mix of torch and numpy arguments')
+            if dev:
+                if not a.is_cuda or not a.is_contiguous():
+                    raise ValueError('device path needs contiguous ROCm tensors')
+                if a.device.index != self.device:
+                    raise ValueError(f'tensor on device {a.device.index}, solver on {self.device}')
+                if tuple(a.shape) != tuple(shp):
+                    raise ValueError(f'argument {i}: shape {tuple(a.shape)} != {tuple(shp)}')
+                ptrs.append(a.data_ptr())
+                keep.append(a)
+            else:
+                dt = np.float64 if dtypes is None else dtypes[i]
+                b = np.ascontiguousarray(a, dt)
+                if tuple(b.shape) != tuple(shp):
+                    raise ValueError(f'argument {i}: shape {tuple(b.shape)} != {tuple(shp)}')
+                ptrs.append(b.ctypes.data)
+                keep.append(b)
+        return ptrs, int(dev), keep
+
+    # -- the hot path ------------------------------------------------------------------------------------------------------
+    def solve(self, x0, x_guess, u_guess, p, out=None):
+        """One SQP-RTI solve per instance (controller.py:136-167).  Returns (x, u, status, qp_iter)."""
+        B = x0.shape[0]
+        N, nx, nu = self.N, self.nx, self.nu
+        shapes = [(B, nx), (B, N + 1, nx), (B, N, nu), (B, N + 1, 5)]
+        ptrs, dev, keep = self._prep([x0, x_guess, u_guess, p], shapes)
+        if dev:
+            import torch
+            if out is None:
+                kw = dict(device=x0.device)
+                out = (torch.empty((B, N + 1, nx), dtype=torch.float64, **kw),
+                       torch.empty((B, N, nu), dtype=torch.float64, **kw),
+                       torch.empty((B,), dtype=torch.int32, **kw), torch.empty((B,), dtype=torch.int32, **kw))
+            op = [o.data_ptr() for o in out]
+        else:
+            if out is None:
+                out = (np.empty((B, N + 1, nx)), np.empty((B, N, nu)), np.empty(B, np.int32), np.empty(B, np.int32))
+            op = [o.ctypes.data for o in out]
+        self._chk(self.L.smpc_solve_batch(self.h, B, *ptrs, *op, dev))
+        return out
+
+    def eval_nodes(self, x_guess, u_guess, p):
+        B = x_guess.shape[0]
+        N, nx, nu = self.N, self.nx, self.nu
+        ptrs, dev, keep = self._prep([x_guess, u_guess, p], [(B, N + 1, nx), (B, N, nu), (B, N + 1, 5)])
+        if dev:
+            raise NotImplementedError('eval_nodes is a host-path diagnostic')
+        out = np.zeros((B, N + 1), NODE_EVAL_DTYPE)
+        self._chk(self.L.smpc_eval_nodes(self.h, B, *ptrs, out.ctypes.data, 0))
+        return out
+
+    # -- callers around the solve (a13, a15, a16) ------------------------------------------------------------------------
+    def guess_correction(self, x_guess, u_guess):
+        """In place on torch tensors; returns a corrected copy for numpy."""
+        B = x_guess.shape[0]
+        if not _is_torch(x_guess):
+            x_guess = np.array(x_guess, np.float64, order='C', copy=True)
+        ptrs, dev, keep = self._prep([x_guess, u_guess], [(B, self.N + 1, self.nx), (B, self.N, self.nu)])
+        self._chk(self.L.smpc_guess_correction(self.h, B, *ptrs, dev))
+        return x_guess
+
+    def provide_control(self, accept, x_temp, u_temp, x_guess, u_guess):
+        B = x_temp.shape[0]
+        N, nx, nu = self.N, self.nx, self.nu
+        if not _is_torch(x_guess):
+            x_guess = np.array(x_guess, np.float64, order='C', copy=True)
+            u_guess = np.array(u_guess, np.float64, order='C', copy=True)
+            u_apply = np.empty((B, nu))
+            accept = np.ascontiguousarray(accept, np.int32)
+        else:
+            import torch
+            u_apply = torch.empty((B, nu), dtype=torch.float64, device=x_guess.device)
+        ptrs, dev, keep = self._prep([accept, x_temp, u_temp, x_guess, u_guess, u_apply],
+                                     [(B,), (B, N + 1, nx), (B, N, nu), (B, N + 1, nx), (B, N, nu), (B, nu)],
+                                     [np.int32] + [np.float64] * 5)
+        if not dev:
+            # _prep may have re-wrapped the arrays; make sure outputs are the ones we return
+            ptrs[3], ptrs[4], ptrs[5] = x_guess.ctypes.data, u_guess.ctypes.data, u_apply.ctypes.data
+        self._chk(self.L.smpc_provide_control(self.h, B, *ptrs, dev))
+        return x_guess, u_guess, u_apply
+
+    def check_trajectory(self, x, x_min=None, x_max=None, tol_x=None, row_lb=None, row_ub=None, alpha=None,
+                         tol_safe=None, want_nn=False):
+        """checkStateConstraints (env_model.py:170-173) per instance; optionally the safe-set test per node."""
+        pr, par = self.problem, self.problem.params
+        x_min = pr.x_min if x_min is None else x_min
+        x_max = pr.x_max if x_max is None else x_max
+        tol_x = par.tol_x if tol_x is None else tol_x
+        row_lb = pr.row_check[:, 0] if row_lb is None else row_lb
+        row_ub = pr.row_check[:, 1] if row_ub is None else row_ub
+        alpha = par.alpha if alpha is None else alpha
+        tol_safe = par.tol_safe_set if tol_safe is None else tol_safe
+        B, n_nodes = x.shape[0], x.shape[1]
+        small = [np.ascontiguousarray(a, np.float64) for a in (x_min, x_max, row_lb, row_ub)]
+        if _is_torch(x):
+            import torch
+            ok = torch.empty((B,), dtype=torch.int32, device=x.device)
+            nn = torch.empty((B, n_nodes), dtype=torch.int32, device=x.device) if want_nn else None
+            self._chk(self.L.smpc_check_trajectory(self.h, B, n_nodes, x.data_ptr(), small[0].ctypes.data,
+                                                   small[1].ctypes.data, tol_x, small[2].ctypes.data,
+                                                   small[3].ctypes.data, alpha, tol_safe, ok.data_ptr(),
+                                                   nn.data_ptr() if want_nn else None, 1))
+            return (ok, nn) if want_nn else ok
+        xx = np.ascontiguousarray(x, np.float64)
+        ok = np.empty(B, np.int32)
+        nn = np.empty((B, n_nodes), np.int32) if want_nn else None
+        self._chk(self.L.smpc_check_trajectory(self.h, B, n_nodes, xx.ctypes.data, small[0].ctypes.data,
+                                               small[1].ctypes.data, tol_x, small[2].ctypes.data, small[3].ctypes.data,
+                                               alpha, tol_safe, ok.ctypes.data, nn.ctypes.data if want_nn else None, 0))
+        return (ok.astype(bool), nn.astype(bool)) if want_nn else ok.astype(bool)
+
+    def plant_step(self, x, u, joints_noisy=None, tau_noise=None):
+        """AdamModel.integrate (env_model.py:192-206) for B instances."""
+        B = x.shape[0]
+        if _is_torch(x):
+            import torch
+            xn = torch.empty_like(x)
+            ue = torch.empty_like(u)
+            jn = joints_noisy.data_ptr() if joints_noisy is not None else None
+            tn = tau_noise.data_ptr() if tau_noise is not None else None
+            self._chk(self.L.smpc_plant_step(self.h, B, x.data_ptr(), u.data_ptr(), jn, tn, xn.data_ptr(),
+                                             ue.data_ptr(), 1))
+            return xn, ue
+        xx, uu = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(u, np.float64)
+        xn, ue = np.empty_like(xx), np.empty_like(uu)
+        jn = tn = None
+        if joints_noisy is not None:
+            joints_noisy = np.ascontiguousarray(joints_noisy, JOINT_DTYPE)
+            assert joints_noisy.shape == (B, self.nq)
+            jn = joints_noisy.ctypes.data
+        if tau_noise is not None:
+            tau_noise = np.ascontiguousarray(tau_noise, np.float64)
+            tn = tau_noise.ctypes.data
+        self._chk(self.L.smpc_plant_step(self.h, B, xx.ctypes.data, uu.ctypes.data, jn, tn, xn.ctypes.data,
+                                         ue.ctypes.data, 0))
+        return xn, ue

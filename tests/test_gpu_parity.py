@@ -1,0 +1,158 @@
+"""Parity of the HIP engine (through the C ABI) with the CPU oracle on identical seeded inputs.  -m gpu only.
+
+Tolerances (FP64 paths are compared tightly; rows that pass through the fp32 network inherit its rounding):
+  linearisation pieces ...... 1e-9 relative to the field's scale
+  fp32 MLP value / gradient . 2e-5 relative
+  RTI solution without NN ... 1e-6 * (1 + |u|_inf)  (two IPMs converging to one QP solution from rounding-different paths)
+  RTI solution with NN ...... 1e-4 * (1 + |u|_inf)
+"""
+import numpy as np
+import pytest
+
+from conftest import constant_guess, make_problem, sample_instances
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(prob, net):
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    return BatchedOcpSolver(prob, net)
+
+
+def _oracle(prob, net):
+    from oracle.oracle import Oracle
+    return Oracle(prob, (net.weights, net.biases))
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
+
+
+@pytest.mark.parametrize('controller,cost', [('naive', 'ext'), ('constraint_everywhere', 'nls')])
+def test_eval_nodes_parity(controller, cost):
+    par, prob, net = make_problem(controller, cost, N=12)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    x0 = sample_instances(prob, 24, seed=1, vel_scale=0.5)
+    xg, ug, p = constant_guess(prob, x0)
+    rng = np.random.default_rng(0)
+    xg[:, 1:] += 0.05 * rng.standard_normal(xg[:, 1:].shape)
+    ug += rng.uniform(-5, 5, ug.shape)
+    a, b = s.eval_nodes(xg, ug, p), o.eval_nodes(xg, ug, p)
+    nq = 6
+    for f, n in [('tau', nq), ('M', 36), ('dtau_dq', 36), ('dtau_dv', 36), ('ee', 3), ('cost_grad_q', nq),
+                 ('cost_hess_qq', 36), ('row_val', 6), ('row_grad', 36)]:
+        assert _rel(a[f][..., :n], b[f][..., :n]) < 1e-9, f
+    if controller != 'naive':
+        assert _rel(a['nn_val'], b['nn_val']) < 2e-5
+        assert _rel(a['nn_grad'][..., :12], b['nn_grad'][..., :12]) < 2e-4
+        assert np.all(a['nn_val'][:, 0] == 0)        # node 0 never carries the row
+
+
+@pytest.mark.parametrize('controller,cost,N,tol', [('naive', 'ext', 30, 1e-6), ('zerovel', 'nls', 20, 1e-6),
+                                                   ('st', 'ext', 30, 1e-4), ('htwa', 'ext', 15, 1e-4),
+                                                   ('constraint_everywhere', 'ext', 10, 1e-4),
+                                                   ('receding', 'ext', 12, 1e-4), ('backup', 'ext', 25, 1e-6)])
+def test_rti_solve_parity(controller, cost, N, tol):
+    par, prob, net = make_problem(controller, cost, N=N)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    B = 32
+    x0 = sample_instances(prob, B, seed=2, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    if controller == 'receding':
+        p[:, 1:N, 4] = -1.0
+        p[np.arange(B), 1 + np.arange(B) % (N - 1), 4] = 1.0      # one switched-on running node per instance
+    xa, ua, sa, ia = s.solve(x0, xg, ug, p)
+    xb, ub, sb, ib = o.solve_batch(x0, xg, ug, p)
+    assert np.array_equal(sa, sb)
+    ok = sb == 0
+    assert ok.sum() >= B - 2
+    assert np.abs(ia[ok] - ib[ok]).max() <= 2
+    scale = 1 + np.abs(ub[ok]).max()
+    assert np.abs(ua[ok] - ub[ok]).max() < tol * scale
+    assert np.abs(xa[ok] - xb[ok]).max() < tol
+    # second step from the shifted solution with a perturbed measured state (x0 != x_guess[0])
+    xg2, ug2, _ = o.provide_control(np.ones(B, np.int32), xb, ub, xg, ug)
+    xg2 = o.guess_correction(xg2, ug2)
+    x1 = xg2[:, 0] + 1e-3 * np.random.default_rng(1).standard_normal((B, 12))
+    xa, ua, sa, ia = s.solve(x1, xg2, ug2, p)
+    xb, ub, sb, ib = o.solve_batch(x1, xg2, ug2, p)
+    assert np.array_equal(sa, sb)
+    ok = sb == 0
+    assert np.abs(ua[ok] - ub[ok]).max() < tol * (1 + np.abs(ub[ok]).max())
+
+
+def test_callers_parity():
+    par, prob, net = make_problem('st', N=10)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    B = 16
+    rng = np.random.default_rng(3)
+    x0 = sample_instances(prob, B, seed=3, vel_scale=0.3)
+    xg, ug, p = constant_guess(prob, x0)
+    ug += rng.uniform(-3, 3, ug.shape)
+    assert np.allclose(s.guess_correction(xg, ug), o.guess_correction(xg, ug), atol=1e-13)
+    xt, ut = xg + 0.1, ug - 0.2
+    acc = (np.arange(B) % 2).astype(np.int32)
+    a, b = s.provide_control(acc, xt, ut, xg, ug), o.provide_control(acc, xt, ut, xg, ug)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    # feasibility predicates on a trajectory that leaves the box for some instances
+    traj = o.guess_correction(xg, ug * 40)
+    ok_a, nn_a = s.check_trajectory(traj, want_nn=True)
+    ok_b, nn_b = o.check_trajectory(traj, prob.x_min, prob.x_max, par.tol_x, prob.row_check[:, 0], prob.row_check[:, 1],
+                                    par.alpha, par.tol_safe_set, want_nn=True)
+    assert np.array_equal(ok_a, ok_b) and 0 < ok_b.sum() < B
+    assert (nn_a != nn_b).mean() < 0.01
+    # plant step, nominal and with perturbed inertias + torque noise
+    u = rng.uniform(-10, 10, (B, 6))
+    xa, ea = s.plant_step(x0, u)
+    xb, eb = o.plant_step(x0, u)
+    assert np.allclose(xa, xb, atol=1e-10) and np.allclose(ea, eb, atol=1e-8)
+    jt = np.tile(prob.joint_table(), (B, 1))
+    jt['mass'] *= 1 + 0.1 * rng.uniform(-1, 1, jt['mass'].shape)
+    jt['com'] *= 1 + 0.1 * rng.uniform(-1, 1, jt['com'].shape)
+    tn = rng.normal(0, 0.5, (B, 6))
+    xa, ea = s.plant_step(x0, u * 5, jt, tn)
+    xb, eb = o.plant_step(x0, u * 5, jt, tn)
+    assert np.allclose(xa, xb, atol=1e-10) and np.allclose(ea, eb, atol=1e-7)
+
+
+def test_full_size_properties():
+    """BASELINE config 1 size (B=4096, N=30, 'st'): properties that need no oracle run."""
+    par, prob, net = make_problem('st', N=30)
+    s = _solver(prob, net)
+    B = 4096
+    x0 = sample_instances(prob, B, seed=4)
+    xg, ug, p = constant_guess(prob, x0)
+    x, u, st, it = s.solve(x0, xg, ug, p)
+    assert (st == 0).mean() > 0.99
+    ok = st == 0
+    assert np.allclose(x[:, 0], x0, atol=1e-12)
+    dt = par.dt
+    assert np.allclose(x[ok, 1:, :6], x[ok, :-1, :6] + dt * x[ok, :-1, 6:] + 0.5 * dt * dt * u[ok], atol=1e-9)
+    assert np.allclose(x[ok, 1:, 6:], x[ok, :-1, 6:] + dt * u[ok], atol=1e-9)
+    assert np.all(x[ok, 1:] >= prob.lbx - 1e-6) and np.all(x[ok, 1:] <= prob.ubx + 1e-6)
+    # determinism and batch-independence: a sub-batch gives bit-identical results
+    x2, u2, st2, it2 = s.solve(x0[:100], xg[:100], ug[:100], p[:100])
+    assert np.array_equal(x2, x[:100]) and np.array_equal(u2, u[:100]) and np.array_equal(it2, it[:100])
+    # spot parity against the oracle on a slice
+    from oracle.oracle import Oracle
+    o = Oracle(prob, (net.weights, net.biases))
+    xb, ub, sb, ib = o.solve_batch(x0[:64], xg[:64], ug[:64], p[:64])
+    assert np.array_equal(sb, st[:64])
+    assert np.abs(ub - u[:64]).max() < 1e-4 * (1 + np.abs(ub).max())
+
+
+def test_device_pointer_path_matches_host_path():
+    import torch
+    par, prob, net = make_problem('st', N=30)
+    s = _solver(prob, net)
+    B = 256
+    x0 = sample_instances(prob, B, seed=5)
+    xg, ug, p = constant_guess(prob, x0)
+    xh, uh, sh, ih = s.solve(x0, xg, ug, p)
+    dev = torch.device('cuda:0')
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    xd, ud, sd, idd = s.solve(t(x0), t(xg), t(ug), t(p))
+    s.sync()
+    assert np.array_equal(xd.cpu().numpy(), xh) and np.array_equal(ud.cpu().numpy(), uh)
+    assert np.array_equal(sd.cpu().numpy(), sh)
