@@ -236,8 +236,12 @@ class OcpProblem:
         d.hessian = HESS_EXACT if cost == 'ext' else HESS_GAUSS_NEWTON
         d.Q, d.R = params.Q_weight, params.R_weight
         d.cost_scale_stage, d.cost_scale_term = params.dt, 1.0
-        lm = 0.0 if controller == 'backup' else params.levenberg_marquardt          # controller.py:711
-        d.lm_stage, d.lm_term = lm * params.dt, lm
+        # controller.py:711 sets LM = 0 for the backup OCP, whose cost is zero as well: the QP Hessian vanishes and the
+        # reference relies on HPIPM's internal primal regularisation [EXT-UNVERIFIED].  The engine states it: a 1e-4
+        # diagonal makes the QP strictly convex (minimum-norm feasible correction of the guess) and well enough
+        # conditioned that its solution is resolved at the IPM's 1e-8 exit tolerance.
+        lm = 1e-4 / params.dt if controller == 'backup' else params.levenberg_marquardt
+        d.lm_stage, d.lm_term = lm * params.dt, (1e-4 if controller == 'backup' else lm)
 
         # safe set (safe_set.py:72-104)
         d.nn_mode, d.nn_dof, d.nn_eps = nn_mode, params.n_dof_safe_set, params.eps

@@ -5,6 +5,10 @@ Tolerances (FP64 paths are compared tightly; rows that pass through the fp32 net
   fp32 MLP value / gradient . 2e-5 relative
   RTI solution without NN ... 1e-6 * (1 + |u|_inf)  (two IPMs converging to one QP solution from rounding-different paths)
   RTI solution with NN ...... 1e-4 * (1 + |u|_inf)
+  terminal q_dot = 0 ........ 2e-5 * (1 + |u|_inf)  (zerovel pins the velocity with lb == ub: the two barrier terms of
+                              a zero-width box make the last Newton systems ill-conditioned)
+  backup OCP ................ 5e-4 * (1 + |u|_inf)  (zero cost: the only curvature is the 1e-4 regularisation, so the
+                              minimiser is resolved to about sqrt(tol_ipm / 1e-4) only -- a feasibility problem)
 """
 import numpy as np
 import pytest
@@ -48,10 +52,10 @@ def test_eval_nodes_parity(controller, cost):
         assert np.all(a['nn_val'][:, 0] == 0)        # node 0 never carries the row
 
 
-@pytest.mark.parametrize('controller,cost,N,tol', [('naive', 'ext', 30, 1e-6), ('zerovel', 'nls', 20, 1e-6),
+@pytest.mark.parametrize('controller,cost,N,tol', [('naive', 'ext', 30, 1e-6), ('zerovel', 'nls', 20, 2e-5),
                                                    ('st', 'ext', 30, 1e-4), ('htwa', 'ext', 15, 1e-4),
                                                    ('constraint_everywhere', 'ext', 10, 1e-4),
-                                                   ('receding', 'ext', 12, 1e-4), ('backup', 'ext', 25, 1e-6)])
+                                                   ('receding', 'ext', 12, 1e-4), ('backup', 'ext', 25, 5e-4)])
 def test_rti_solve_parity(controller, cost, N, tol):
     par, prob, net = make_problem(controller, cost, N=N)
     s, o = _solver(prob, net), _oracle(prob, net)
@@ -69,7 +73,7 @@ def test_rti_solve_parity(controller, cost, N, tol):
     assert np.abs(ia[ok] - ib[ok]).max() <= 2
     scale = 1 + np.abs(ub[ok]).max()
     assert np.abs(ua[ok] - ub[ok]).max() < tol * scale
-    assert np.abs(xa[ok] - xb[ok]).max() < tol
+    assert np.abs(xa[ok] - xb[ok]).max() < max(tol, 1e-6)
     # second step from the shifted solution with a perturbed measured state (x0 != x_guess[0])
     xg2, ug2, _ = o.provide_control(np.ones(B, np.int32), xb, ub, xg, ug)
     xg2 = o.guess_correction(xg2, ug2)
@@ -96,7 +100,16 @@ def test_callers_parity():
     for u, v in zip(a, b):
         assert np.array_equal(u, v)
     # feasibility predicates on a trajectory that leaves the box for some instances
-    traj = o.guess_correction(xg, ug * 40)
+    traj = o.guess_correction(xg, ug)
+    traj[::4, 5, 2] += 10.0                                  # out of the joint box
+    q_hit = None                                             # a configuration the collision rows reject
+    for q in rng.uniform(prob.lbx[:6], prob.ubx[:6], (4000, 6)):
+        xq = np.concatenate([q, np.zeros(6)])[None, None]
+        if not o.check_trajectory(xq, prob.x_min, prob.x_max, par.tol_x, prob.row_check[:, 0], prob.row_check[:, 1])[0]:
+            q_hit = q
+            break
+    assert q_hit is not None
+    traj[1, 7, :6] = q_hit
     ok_a, nn_a = s.check_trajectory(traj, want_nn=True)
     ok_b, nn_b = o.check_trajectory(traj, prob.x_min, prob.x_max, par.tol_x, prob.row_check[:, 0], prob.row_check[:, 1],
                                     par.alpha, par.tol_safe_set, want_nn=True)
