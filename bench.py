@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- RTI-MPC throughput of the HIP engine on BASELINE.json's headline workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one closed-loop RTI-MPC step of the whole batch, all inputs resident in HBM:
+guessCorrection -> SQP-RTI solve (linearise, MLP, QP) -> accept test -> provideControl -> plant step
+(reference controller.py:274-284 + scripts/mpc.py:151,240 for every instance at once).
+
+Workload (config.workload = "C1"): Z1-class 6-DoF, N = 30, 4096 OCP instances per GPU, controller 'st'
+(terminal soft safe-set row through the 12-256-256-256-1 GELU MLP), EXTERNAL cost with exact Hessian, 6 capsule pairs,
+Halton initial states, constant first guess -- SURVEY 8(d).  Weak scaling: every rank owns 4096 instances; the only
+exchange is one RCCL gather of the applied controls + statuses per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline:     algorithmic HBM bytes of the dominant kernel (k_qp_ipm) / its HIP-event duration vs 8 TB/s
+  cpu_baseline: the CPU oracle (a port, not acados) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 4096
+HORIZON = 30
+CONTROLLER = 'st'
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes(nq, N):
+    """inputs read once + outputs written once, FP64, per instance-step."""
+    nx, nu = 2 * nq, nq
+    return 8 * (nx + (N + 1) * nx + N * nu + (N + 1) * 5) + 8 * ((N + 1) * nx + N * nu) + 4
+
+
+def build_problem():
+    from safe_mpc_amd.parser import Parameters
+    from safe_mpc_amd.problem import OcpProblem
+    from safe_mpc_amd.safe_set import SafeSetNet
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.N = 6, 6, HORIZON
+    par.net_size = [12, 256, 1]
+    prob = OcpProblem(par, CONTROLLER, 'ext', N=HORIZON)
+    net = SafeSetNet.from_params(par, prob.x_min, prob.x_max)
+    prob.set_normalisation(net.mean, net.std)
+    return par, prob, net
+
+
+def halton(n, dim, skip):
+    primes = [2, 3, 5, 7, 11, 13, 17]
+    idx = np.arange(skip, skip + n)
+    out = np.zeros((n, dim))
+    for d in range(dim):
+        b, f, k = primes[d], 1.0, idx.copy()
+        r = np.zeros(n)
+        while k.max() > 0:
+            f /= b
+            r += f * (k % b)
+            k //= b
+        out[:, d] = r
+    return out
+
+
+def initial_states(solver, prob, B, rank):
+    """Halton q0 in the joint box (guess_acados.py:79,100), collision filter through the engine (guess_acados.py:109)."""
+    nq = prob.nq
+    lo, hi = prob.lbx[:nq] + 0.05, prob.ubx[:nq] - 0.05
+    xs, skip = [], 1 + rank * 16 * B
+    while sum(len(x) for x in xs) < B:
+        q = lo + halton(2 * B, nq, skip) * (hi - lo)
+        skip += 2 * B
+        x = np.hstack([q, np.zeros((2 * B, nq))])
+        ok = solver.check_trajectory(x[:, None, :], tol_x=0.0, row_lb=prob.row_lb, row_ub=prob.row_ub)
+        xs.append(x[ok])
+    return np.vstack(xs)[:B]
+
+
+def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=12.0):
+    """CPU port (oracle/) on this host's cores: bounded sample of the same workload, same first RTI step."""
+    from oracle.oracle import Oracle, build
+    build()
+    o = Oracle(prob, (net.weights, net.biases))
+    cores = len(os.sched_getaffinity(0))
+    chunk, done = min(len(x0), 8 * cores), 0
+    o.solve_batch(x0[:cores], xg[:cores], ug[:cores], p[:cores])      # warm the code path
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:                         # cycle through the sample until the budget is used
+        lo = done % (len(x0) - chunk + 1)
+        sl = slice(lo, lo + chunk)
+        o.solve_batch(x0[sl], xg[sl], ug[sl], p[sl])
+        done += chunk
+    dt = time.perf_counter() - t0
+    return {'value': done / dt, 'unit': 'instance-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{done} instance-solves drawn cyclically from {len(x0)} C1 instances (first RTI step), OpenMP over instances, '
+                      f'{dt:.1f} s; oracle/smpc_oracle.cpp -O3, a CPU restatement -- not acados'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='instances per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    par, prob, net = build_problem()
+    solver = BatchedOcpSolver(prob, net, device=local)
+    B, N, nx, nu = args.batch, HORIZON, prob.nx, prob.nu
+
+    x0_h = initial_states(solver, prob, B, rank)
+    xg_h = np.repeat(x0_h[:, None, :], N + 1, axis=1)
+    ug_h = np.zeros((B, N, nu))
+    p_h = np.zeros((B, N + 1, 5))
+    p_h[:, :, :3], p_h[:, :, 3], p_h[:, :, 4] = prob.ee_ref, par.alpha, 1.0
+
+    stream = torch.cuda.ExternalStream(solver.L.smpc_stream(solver.h), device=dev)
+    t = lambda a, dt=torch.float64: torch.tensor(a, dtype=dt, device=dev)
+    with torch.cuda.stream(stream):
+        x_sim, xg, ug, p = t(x0_h), t(xg_h), t(ug_h), t(p_h)
+        out = (torch.empty_like(xg), torch.empty_like(ug), torch.empty(B, dtype=torch.int32, device=dev),
+               torch.empty(B, dtype=torch.int32, device=dev))
+        gather_buf = [torch.empty((B, nu + 1), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
+    iters_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    fail_sum = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def step(first):
+        nonlocal x_sim, xg, ug
+        with torch.cuda.stream(stream):
+            if not first:
+                solver.guess_correction(xg, ug)                                   # controller.py:226-231
+            xt, ut, st, it = solver.solve(x_sim, xg, ug, p, out=out)             # controller.py:136-167
+            accept = (st == 0).to(torch.int32)                                    # NaiveController.step (:279-283)
+            xg, ug, u_apply = solver.provide_control(accept, xt, ut, xg, ug)      # controller.py:169-184
+            x_sim, _ = solver.plant_step(x_sim, u_apply)                          # env_model.py:192-206 (nominal plant)
+            iters_sum.add_(it.sum())
+            fail_sum.add_((st != 0).sum())
+            if world > 1:                                                         # the single result gather
+                payload = torch.cat([u_apply, st.to(torch.float64)[:, None]], dim=1)
+                dist.gather(payload, gather_buf, dst=0)
+
+    def barrier():
+        solver.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        solver.sync()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(first=(i == 0))
+    iters_sum.zero_()
+    fail_sum.zero_()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(first=(args.warmup == 0 and i == 0))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    mean_iter = float(iters_sum.item()) / (B * max(args.steps, 1))
+    fails = float(fail_sum.item())
+
+    # roofline probe of the dominant kernel (k_qp_ipm): HIP events on the engine's stream around each phase
+    roof = None
+    if rank == 0:
+        solver.enable_timing(True)
+        acc = np.zeros(4)
+        probes = min(5, max(args.steps, 1))
+        for _ in range(probes):
+            with torch.cuda.stream(stream):
+                solver.guess_correction(xg, ug)
+                solver.solve(x_sim, xg, ug, p, out=out)
+            tm = solver.timing()
+            acc += [tm['time_lin'], tm['time_nn'], tm['time_qp'], tm['time_tot']]
+        solver.enable_timing(False)
+        acc /= probes
+        alg = algorithmic_bytes(prob.nq, N) * B
+        ach = alg / acc[2] / 1e9
+        roof = {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                'kernel_ms': {'linearise': acc[0] * 1e3, 'mlp': acc[1] * 1e3, 'qp': acc[2] * 1e3, 'solve_total': acc[3] * 1e3},
+                'algorithmic_bytes_per_launch': alg}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nb = min(B, 2048)
+        cpu = cpu_baseline(prob, net, x0_h[:nb], xg_h[:nb], ug_h[:nb], p_h[:nb])
+
+    if rank == 0:
+        total = B * world * args.steps
+        line = {
+            'metric': 'RTI-MPC instance-steps/s (batch=4096 per GPU, Z1 N=30)',
+            'value': total / elapsed, 'unit': 'instance-steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C1: Z1-class 6-DoF, N=30, 4096 instances/GPU, controller st (soft terminal NN row, '
+                                   'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',
+                       'batch_per_gpu': B, 'horizon': N, 'controller': CONTROLLER,
+                       'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
+                       'failed_instance_steps': fails},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
