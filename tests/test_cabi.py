@@ -14,7 +14,7 @@ def test_library_exports_every_declared_symbol():
         _lib.build()
     L = C.CDLL(_lib.LIB_PATH)
     hdr = open(os.path.join(ROOT, 'include', 'smpc.h')).read()
-    declared = set(re.findall(r'\b(smpc_[a-z_]+)\s*\(', hdr))
+    declared = set(re.findall(r'^(?:int|void|void\*|const char\*)\s+(smpc_[a-z_]+)\s*\(', hdr, re.M))
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
