@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -646,6 +647,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
     };
 
     /* The vector recursion needs P_{k+1} applied to nothing but b (kept as Pb) -- p_k only involves W, w. */
+    double corr_w = 1.0;
     auto solve = [&](double sigma_mu, bool corrector) {
         /* gradient  g + C^T e */
         for (int k = 0; k <= N; k++) {
@@ -655,10 +657,10 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
             for (int r = 0; r < s.nr; r++) {
                 double e = 0.0;
                 if (s.has_lo[r]) {
-                    double ct = corrector ? s.dtl[r] * s.dll[r] : 0.0;
+                    double ct = corrector ? corr_w * s.dtl[r] * s.dll[r] : 0.0;
                     if (s.soft[r] >= 0.0) {
                         double nu_ = s.soft[r] - s.ll[r];
-                        double cs = corrector ? -s.dsl[r] * s.dll[r] : 0.0;  // d_nu = -d_lambda
+                        double cs = corrector ? -corr_w * s.dsl[r] * s.dll[r] : 0.0;  // d_nu = -d_lambda
                         double deff = 1.0 / (s.tl[r] / s.ll[r] + s.sl[r] / nu_);
                         e += -s.ll[r] + deff * (-s.lo[r] + (sigma_mu - cs) / nu_ - (sigma_mu - ct) / s.ll[r]);
                     } else {
@@ -666,7 +668,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
                     }
                 }
                 if (s.has_hi[r]) {
-                    double ct = corrector ? s.dtu[r] * s.dlu[r] : 0.0;
+                    double ct = corrector ? corr_w * s.dtu[r] * s.dlu[r] : 0.0;
                     e += s.lu[r] - (s.lu[r] / s.tu[r]) * s.hi[r] + (sigma_mu - ct) / s.tu[r];
                 }
                 if (e == 0.0) continue;
@@ -728,10 +730,10 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
                 double czn = 0.0;
                 for (int i = 0; i < nz; i++) czn += s.Cm[r][i] * s.zn[i];
                 if (s.has_lo[r]) {
-                    double ct = corrector ? s.dtl[r] * s.dll[r] : 0.0;
+                    double ct = corrector ? corr_w * s.dtl[r] * s.dll[r] : 0.0;
                     if (s.soft[r] >= 0.0) {
                         double nu_ = s.soft[r] - s.ll[r];
-                        double cs = corrector ? -s.dsl[r] * s.dll[r] : 0.0;
+                        double cs = corrector ? -corr_w * s.dsl[r] * s.dll[r] : 0.0;
                         double deff = 1.0 / (s.tl[r] / s.ll[r] + s.sl[r] / nu_);
                         double dl = -deff * (czn - s.lo[r] + (sigma_mu - cs) / nu_ - (sigma_mu - ct) / s.ll[r]);
                         double dt_ = (sigma_mu - ct - s.tl[r] * dl) / s.ll[r] - s.tl[r];
@@ -744,7 +746,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
                     }
                 }
                 if (s.has_hi[r]) {
-                    double ct = corrector ? s.dtu[r] * s.dlu[r] : 0.0;
+                    double ct = corrector ? corr_w * s.dtu[r] * s.dlu[r] : 0.0;
                     double dt_ = s.hi[r] - czn - s.tu[r];
                     s.dlu[r] = (sigma_mu - ct - s.lu[r] * dt_) / s.tu[r] - s.lu[r];
                     s.dtu[r] = dt_;
@@ -792,6 +794,9 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         double mu_aff = acc / m_comp;
         double sigma = mu_aff / mu;
         sigma = sigma * sigma * sigma;
+        /* safeguard against Mehrotra cycling: the second-order term models a FULL affine step; when the affine step is
+         * blocked early (a_aff < 0.3) it is scaled by a_aff^2, which turns the iteration into a centring step */
+        corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
         /* corrector */
         solve(sigma * mu, true);
         double alpha = std::min(1.0, tau_ftb * max_step());
@@ -812,6 +817,8 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         }
         rho *= (1.0 - alpha);
         mu = mu_now();
+        if (std::getenv("SMPC_ORACLE_TRACE"))
+            std::fprintf(stderr, "it %3d a_aff %.3e sigma %.3e alpha %.3e mu %.3e rho*R0 %.3e\n", it, a_aff, sigma, alpha, mu, rho * R0);
         if (!(mu == mu)) { status = 4; break; }
     }
     if (it == o.max_iter && status == 2 && mu <= o.tol && rho * R0 <= o.tol) status = 0;
