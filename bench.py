@@ -125,6 +125,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
+    from safe_mpc_amd.sharding import gather_to_root
     from safe_mpc_amd.solver import BatchedOcpSolver
     par, prob, net = build_problem()
     solver = BatchedOcpSolver(prob, net, device=local)
@@ -142,7 +143,6 @@ def main():
         x_sim, xg, ug, p = t(x0_h), t(xg_h), t(ug_h), t(p_h)
         out = (torch.empty_like(xg), torch.empty_like(ug), torch.empty(B, dtype=torch.int32, device=dev),
                torch.empty(B, dtype=torch.int32, device=dev))
-        gather_buf = [torch.empty((B, nu + 1), dtype=torch.float64, device=dev) for _ in range(world)] if rank == 0 else None
     iters_sum = torch.zeros((), dtype=torch.float64, device=dev)
     fail_sum = torch.zeros((), dtype=torch.float64, device=dev)
 
@@ -159,7 +159,7 @@ def main():
             fail_sum.add_((st != 0).sum())
             if world > 1:                                                         # the single result gather
                 payload = torch.cat([u_apply, st.to(torch.float64)[:, None]], dim=1)
-                dist.gather(payload, gather_buf, dst=0)
+                gather_to_root(payload, sizes=[B] * world)
 
     def barrier():
         solver.sync()

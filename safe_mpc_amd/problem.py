@@ -271,7 +271,8 @@ class OcpProblem:
     def _capsule_points(self, cap):
         """Two end points of a moving capsule in the frame of the actuated link that carries it
         (env_model.py:131-150: FK_link . Trans(spatial_offset) . Rx Ry Rz . e_i)."""
-        if '_pts' not in cap:
+        cache = self.__dict__.setdefault('_cap_pts', {})
+        if cap['name'] not in cache:
             li, lR, lp = self.chain.frame(cap['link_name'])
             R = np.eye(3)
             if cap.get('rotation_offset') is not None:
@@ -281,8 +282,8 @@ class OcpProblem:
             pts = []
             for e in cap['end_points']:
                 pts.append(self._add_point(li, lp + lR @ (off + R @ np.asarray(e[:3], float))))
-            cap['_pts'] = tuple(pts)
-        return cap['_pts']
+            cache[cap['name']] = tuple(pts)
+        return cache[cap['name']]
 
     def _push_row(self, r, name, chk_lo, chk_hi):
         self.rows.append(r)

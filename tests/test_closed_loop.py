@@ -1,0 +1,74 @@
+"""scripts/mpc.py / guess_acados.py semantics through the CPU test double."""
+import numpy as np
+
+from conftest import make_problem
+from fake_solver import OracleSolver
+from safe_mpc_amd import closed_loop as cl
+from safe_mpc_amd import controller as C
+
+
+def _factories(par, N, hidden=256):
+    def make_controller(name, batch):
+        cls = C.CONTROLLERS[name]
+        ctrl = cls.__new__(cls)
+        prob = C.OcpProblem(par, cls.cont_name, 'ext', N=N)
+        net = C.SafeSetNet.from_params(par, prob.x_min, prob.x_max)
+        prob.set_normalisation(net.mean, net.std)
+        C.AbstractController.__init__(ctrl, par, batch, 'ext', N, solver=OracleSolver(prob, net), net=net)
+        return ctrl
+
+    def make_backup(batch):
+        ctrl = C.SafeBackupController.__new__(C.SafeBackupController)
+        prob = C.OcpProblem(par, 'backup', 'zero', N=par.back_hor)
+        net = C.SafeSetNet.from_params(par, prob.x_min, prob.x_max)
+        C.AbstractController.__init__(ctrl, par, batch, 'zero', par.back_hor, solver=OracleSolver(prob, net), net=net)
+        return ctrl
+    return make_controller, make_backup
+
+
+def test_generate_guess_then_run_mpc():
+    par, prob, net = make_problem('naive', N=8)
+    par.back_hor, par.nlp_max_iter, par.n_steps = 10, 120, 12
+    par.levenberg_marquardt = 1e-3           # the default 0.5 makes full-step SQP crawl (config.yaml:21 comment)
+    mk, mkb = _factories(par, 8)
+    guess, good = cl.generate_guess(par, 'naive', 6, make_controller=mk, sqp_tol=1e-5)
+    assert guess['xg'].shape[1:] == (9, 12) and guess['ug'].shape[1:] == (8, 6)
+    n = guess['xg'].shape[0]
+    assert n >= 1
+    res = cl.run_mpc(par, 'naive', guess['xg'], guess['ug'], make_controller=mk, make_backup=mkb, n_steps=12)
+    assert res['x'].shape == (n, 13, 12) and res['u'].shape == (n, 12, 6)
+    idx = set(res['conv_idx']) | set(res['collisions_idx']) | set(res['unconv_idx']) | set(res['viable_idx'])
+    assert idx == set(range(n))                                  # the taxonomy partitions the instances
+    for i in res['collisions_idx']:
+        assert np.isnan(res['x'][i, -1]).any()                   # broken runs are NaN-padded (mpc.py:114)
+    for i in set(range(n)) - set(res['collisions_idx']):
+        assert np.all(np.isfinite(res['x'][i]))
+
+
+def test_model_noise_tables_and_file_names():
+    par, prob, net = make_problem('st', N=8)
+    jt = cl.perturbed_joint_tables(par, 6, 10.0, [0, 1, 1])
+    base = prob.joint_table()
+    assert jt.shape == (3, 6)
+    assert np.array_equal(jt[1]['mass'], jt[2]['mass'])           # same seed, same plant
+    rel = np.abs(jt[0]['mass'] / base['mass'] - 1)
+    assert np.all(rel <= 0.10 + 1e-12) and rel.max() > 1e-3
+    assert np.array_equal(jt[0]['axis'], base['axis']) and np.array_equal(jt[0]['p0'], base['p0'])
+    zero = cl.perturbed_joint_tables(par, 6, 0.0, [5])
+    assert np.allclose(zero[0]['mass'], base['mass']) and np.allclose(zero[0]['inertia'], base['inertia'])
+    f = cl.guess_file(par, 'z1', 'st', 30, True)
+    assert f.endswith('z1_st_30hor_10sm_use_netTrue__q_collision_margins_0.0_0.0_guess.pkl')
+    g = cl.result_file(par, 'z1', 'st', 30, True, 5.0, 1.0, 0.0, 0.0)
+    assert g.endswith('z1_st_use_netTrue_30hor_10sm_noise_5.0_control_noise1.0_q_collision_margins_0.0_0.0_mpc.pkl')
+
+
+def test_masked_step_leaves_inactive_rows_untouched():
+    par, prob, net = make_problem('htwa', N=6)
+    mk, _ = _factories(par, 6)
+    c = mk('htwa', 3)
+    x0 = np.tile(np.concatenate([0.5 * (prob.lbx[:6] + prob.ubx[:6]), np.zeros(6)]), (3, 1))
+    c.setGuess(np.repeat(x0[:, None, :], 7, 1), np.zeros((3, 6, 6)))
+    before = (c.x_guess.copy(), c.fails.copy(), c.current_step.copy())
+    u, ab = cl._masked_step(c, x0, np.array([True, False, True]))
+    assert np.array_equal(c.x_guess[1], before[0][1]) and c.current_step.tolist() == [1, 0, 1]
+    assert not ab[1]

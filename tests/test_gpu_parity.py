@@ -169,3 +169,40 @@ def test_device_pointer_path_matches_host_path():
     s.sync()
     assert np.array_equal(xd.cpu().numpy(), xh) and np.array_equal(ud.cpu().numpy(), uh)
     assert np.array_equal(sd.cpu().numpy(), sh)
+
+
+def test_policy_layer_and_scripts_on_engine(tmp_path):
+    """The batched controllers + run_mpc on the real engine agree with the same code on the CPU test double."""
+    from fake_solver import OracleSolver
+    from safe_mpc_amd import closed_loop as cl
+    from safe_mpc_amd import controller as C
+    from safe_mpc_amd.parser import Parameters
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N, par.back_hor = 6, 6, [12, 256, 1], 10, 12
+    prob0 = C.OcpProblem(par, 'htwa', 'ext', N=10)
+    x0 = sample_instances(prob0, 12, seed=9)
+    xg = np.repeat(x0[:, None, :], 11, axis=1)
+    ug = np.zeros((12, 10, 6))
+
+    def cpu_ctrl(name, batch):
+        cls = C.CONTROLLERS[name]
+        c = cls.__new__(cls)
+        prob = C.OcpProblem(par, cls.cont_name, 'ext', N=10)
+        net = C.SafeSetNet.from_params(par, prob.x_min, prob.x_max)
+        prob.set_normalisation(net.mean, net.std)
+        C.AbstractController.__init__(c, par, batch, 'ext', 10, solver=OracleSolver(prob, net), net=net)
+        return c
+
+    def cpu_backup(batch):
+        c = C.SafeBackupController.__new__(C.SafeBackupController)
+        prob = C.OcpProblem(par, 'backup', 'zero', N=12)
+        C.AbstractController.__init__(c, par, batch, 'zero', 12, solver=OracleSolver(prob, None), net=None)
+        return c
+
+    for name in ('htwa', 'receding'):
+        gpu = cl.run_mpc(par, name, xg, ug, n_steps=15)
+        cpu = cl.run_mpc(par, name, xg, ug, n_steps=15, make_controller=cpu_ctrl, make_backup=cpu_backup)
+        assert gpu['collisions_idx'] == cpu['collisions_idx'] and gpu['viable_idx'] == cpu['viable_idx']
+        both = ~np.isnan(cpu['x']).any(axis=(1, 2))
+        assert both.sum() >= 8
+        assert np.nanmax(np.abs(gpu['x'][both] - cpu['x'][both])) < 1e-4
