@@ -107,6 +107,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='instances per GPU')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='sub-batches per GPU, each on its own HIP stream (fills the tail of the slowest instances)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -125,54 +127,79 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    from safe_mpc_amd.sharding import gather_to_root
+    from safe_mpc_amd.sharding import gather_to_root, shard_range
     from safe_mpc_amd.solver import BatchedOcpSolver
     par, prob, net = build_problem()
-    solver = BatchedOcpSolver(prob, net, device=local)
     B, N, nx, nu = args.batch, HORIZON, prob.nx, prob.nu
+    S = max(1, min(args.streams, B // 256 or 1))
 
-    x0_h = initial_states(solver, prob, B, rank)
+    # one solver handle (= one HIP stream + its own workspace) per sub-batch: independent instances, so the sub-batches
+    # advance independently and the hardware overlaps the long tail of one with the bulk of another
+    solvers = [BatchedOcpSolver(prob, net, device=local) for _ in range(S)]
+    x0_h = initial_states(solvers[0], prob, B, rank)
     xg_h = np.repeat(x0_h[:, None, :], N + 1, axis=1)
     ug_h = np.zeros((B, N, nu))
     p_h = np.zeros((B, N + 1, 5))
     p_h[:, :, :3], p_h[:, :, 3], p_h[:, :, 4] = prob.ee_ref, par.alpha, 1.0
 
-    stream = torch.cuda.ExternalStream(solver.L.smpc_stream(solver.h), device=dev)
     t = lambda a, dt=torch.float64: torch.tensor(a, dtype=dt, device=dev)
-    with torch.cuda.stream(stream):
-        x_sim, xg, ug, p = t(x0_h), t(xg_h), t(ug_h), t(p_h)
-        out = (torch.empty_like(xg), torch.empty_like(ug), torch.empty(B, dtype=torch.int32, device=dev),
-               torch.empty(B, dtype=torch.int32, device=dev))
-    iters_sum = torch.zeros((), dtype=torch.float64, device=dev)
-    fail_sum = torch.zeros((), dtype=torch.float64, device=dev)
+
+    class Sub:
+        pass
+    subs = []
+    for i, sv in enumerate(solvers):
+        lo, hi = shard_range(B, S, i)
+        sb = Sub()
+        sb.solver, sb.n = sv, hi - lo
+        sb.stream = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
+        with torch.cuda.stream(sb.stream):
+            sb.x_sim, sb.xg, sb.ug, sb.p = t(x0_h[lo:hi]), t(xg_h[lo:hi]), t(ug_h[lo:hi]), t(p_h[lo:hi])
+            sb.out = (torch.empty_like(sb.xg), torch.empty_like(sb.ug), torch.empty(sb.n, dtype=torch.int32, device=dev),
+                      torch.empty(sb.n, dtype=torch.int32, device=dev))
+            sb.iters = torch.zeros((), dtype=torch.float64, device=dev)
+            sb.fails = torch.zeros((), dtype=torch.float64, device=dev)
+            sb.payload = torch.empty((sb.n, nu + 1), dtype=torch.float64, device=dev)
+        subs.append(sb)
+    gather_in = torch.empty((B, nu + 1), dtype=torch.float64, device=dev)
 
     def step(first):
-        nonlocal x_sim, xg, ug
-        with torch.cuda.stream(stream):
-            if not first:
-                solver.guess_correction(xg, ug)                                   # controller.py:226-231
-            xt, ut, st, it = solver.solve(x_sim, xg, ug, p, out=out)             # controller.py:136-167
-            accept = (st == 0).to(torch.int32)                                    # NaiveController.step (:279-283)
-            xg, ug, u_apply = solver.provide_control(accept, xt, ut, xg, ug)      # controller.py:169-184
-            x_sim, _ = solver.plant_step(x_sim, u_apply)                          # env_model.py:192-206 (nominal plant)
-            iters_sum.add_(it.sum())
-            fail_sum.add_((st != 0).sum())
-            if world > 1:                                                         # the single result gather
-                payload = torch.cat([u_apply, st.to(torch.float64)[:, None]], dim=1)
-                gather_to_root(payload, sizes=[B] * world)
+        for sb in subs:
+            sv = sb.solver
+            with torch.cuda.stream(sb.stream):
+                if not first:
+                    sv.guess_correction(sb.xg, sb.ug)                                 # controller.py:226-231
+                xt, ut, st, it = sv.solve(sb.x_sim, sb.xg, sb.ug, sb.p, out=sb.out)  # controller.py:136-167
+                accept = (st == 0).to(torch.int32)                                    # NaiveController.step (:279-283)
+                sb.xg, sb.ug, u_apply = sv.provide_control(accept, xt, ut, sb.xg, sb.ug)   # controller.py:169-184
+                sb.x_sim, _ = sv.plant_step(sb.x_sim, u_apply)                        # env_model.py:192-206 (nominal plant)
+                sb.iters.add_(it.sum())
+                sb.fails.add_((st != 0).sum())
+                if world > 1:
+                    sb.payload[:, :nu] = u_apply
+                    sb.payload[:, nu] = st.to(torch.float64)
+        if world > 1:                                                                 # the single result gather
+            for sb in subs:
+                sb.stream.synchronize()
+            off = 0
+            for sb in subs:
+                gather_in[off:off + sb.n] = sb.payload
+                off += sb.n
+            gather_to_root(gather_in, sizes=[B] * world)
 
     def barrier():
-        solver.sync()
+        for sb in subs:
+            sb.solver.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        solver.sync()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(first=(i == 0))
-    iters_sum.zero_()
-    fail_sum.zero_()
+    barrier()
+    for sb in subs:
+        sb.iters.zero_()
+        sb.fails.zero_()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -183,29 +210,35 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    mean_iter = float(iters_sum.item()) / (B * max(args.steps, 1))
-    fails = float(fail_sum.item())
+    mean_iter = sum(float(sb.iters.item()) for sb in subs) / (B * max(args.steps, 1))
+    fails = sum(float(sb.fails.item()) for sb in subs)
 
-    # roofline probe of the dominant kernel (k_qp_ipm): HIP events on the engine's stream around each phase
+    # roofline probe of the dominant kernel (k_qp_ipm): ONE launch over the whole batch, alone on the GPU, HIP events on
+    # the engine's stream around each phase (the per-launch duration rocprofv3 --kernel-trace reports for the same launch)
     roof = None
     if rank == 0:
-        solver.enable_timing(True)
+        sv = BatchedOcpSolver(prob, net, device=local)
+        st_ = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
+        with torch.cuda.stream(st_):
+            xs = torch.cat([sb.x_sim for sb in subs]); xgf = torch.cat([sb.xg for sb in subs])
+            ugf = torch.cat([sb.ug for sb in subs]); pf = torch.cat([sb.p for sb in subs])
+        torch.cuda.synchronize()
+        sv.enable_timing(True)
         acc = np.zeros(4)
-        probes = min(5, max(args.steps, 1))
+        probes = 5
         for _ in range(probes):
-            with torch.cuda.stream(stream):
-                solver.guess_correction(xg, ug)
-                solver.solve(x_sim, xg, ug, p, out=out)
-            tm = solver.timing()
+            with torch.cuda.stream(st_):
+                sv.guess_correction(xgf, ugf)
+                sv.solve(xs, xgf, ugf, pf)
+            tm = sv.timing()
             acc += [tm['time_lin'], tm['time_nn'], tm['time_qp'], tm['time_tot']]
-        solver.enable_timing(False)
         acc /= probes
         alg = algorithmic_bytes(prob.nq, N) * B
         ach = alg / acc[2] / 1e9
         roof = {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': None,
                 'kernel_ms': {'linearise': acc[0] * 1e3, 'mlp': acc[1] * 1e3, 'qp': acc[2] * 1e3, 'solve_total': acc[3] * 1e3},
-                'algorithmic_bytes_per_launch': alg}
+                'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={B}, alone on the GPU'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -221,7 +254,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'C1: Z1-class 6-DoF, N=30, 4096 instances/GPU, controller st (soft terminal NN row, '
                                    'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',
-                       'batch_per_gpu': B, 'horizon': N, 'controller': CONTROLLER,
+                       'batch_per_gpu': B, 'horizon': N, 'controller': CONTROLLER, 'streams_per_gpu': S,
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
                        'failed_instance_steps': fails},
             'roofline': roof, 'cpu_baseline': cpu,

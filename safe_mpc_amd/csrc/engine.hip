@@ -39,6 +39,8 @@ struct smpc_handle {
     smpc_node_eval* d_ev = nullptr;
     double* d_ws = nullptr;
     size_t ws_bytes = 0;
+    int32_t *d_order = nullptr, *d_last_it = nullptr;  // longest-first dispatch order from the previous call's iterations
+    int order_B = 0;                                   // batch size d_last_it is valid for (0 = none yet)
     // staging for host-pointer calls
     int capIO = 0;
     double *d_x0 = nullptr, *d_xg = nullptr, *d_ug = nullptr, *d_p = nullptr, *d_xo = nullptr, *d_uo = nullptr;
@@ -118,6 +120,9 @@ int ensure_batch(smpc_handle* h, int B) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if ((rc = dev_alloc(h, &h->d_ev, (size_t)B * (SMPC_MAX_N + 1)))) return rc;
         if ((rc = dev_alloc(h, &h->d_ws, per * (size_t)B))) return rc;
+        if ((rc = dev_alloc(h, &h->d_order, (size_t)B))) return rc;
+        if ((rc = dev_alloc(h, &h->d_last_it, (size_t)B))) return rc;
+        h->order_B = 0;
         h->ws_bytes = need;
         h->capB = B;
         h->capIO = 0;
@@ -232,8 +237,20 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     int rc;
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
     if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev))) return rc;
-    hipLaunchKernelGGL((k_qp_ipm<NQ>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, h->d_lo,
-                       h->d_hi, h->d_ev, h->d_ws, xo, uo, st, it);
+    // fast path: the row count of the reference's default geometry (6 capsule pairs, config.yaml:205-216) is a
+    // compile-time constant of the kernel; any other geometry takes the runtime-row-count instantiation
+    const int32_t* order = nullptr;
+    if (h->order_B == B && B > 1) {
+        hipLaunchKernelGGL(k_order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->d_last_it, h->d_order);
+        order = h->d_order;
+    }
+    if (h->desc.n_rows == 6)
+        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, h->d_lo,
+                           h->d_hi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it);
+    else
+        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, h->d_lo,
+                           h->d_hi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it);
+    h->order_B = B;
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream));
     return SMPC_OK;
@@ -304,7 +321,7 @@ void smpc_destroy(smpc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_desc, h->d_lo, h->d_hi, h->d_ev, h->d_ws, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
+    void* ptrs[] = {h->d_desc, h->d_lo, h->d_hi, h->d_ev, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
                     h->d_st, h->d_it, h->d_S, h->d_y, h->d_GS, h->d_dA, h->d_dB, h->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < SMPC_MAX_LAYERS; l++) {

@@ -17,6 +17,8 @@
 // The algorithm is the one restated in oracle/smpc_oracle.cpp::qp_ipm (same initial point, Mehrotra rule, step rule and
 // exit test), so the two agree to rounding; the implementation shares nothing with it.
 #pragma once
+#include <type_traits>
+
 #include "device_model.hpp"
 
 namespace smpc {
@@ -118,28 +120,32 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 
 #ifndef QP_WAVES_PER_EU
-#define QP_WAVES_PER_EU 3
+#define QP_WAVES_PER_EU 2
 #endif
 constexpr int QP_PF = 5;  // 16-byte prefetch registers per lane: 5 * 64 * 2 = 640 doubles >= any record
 
-template <int NQ>
+template <int NQ, int MRT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER_EU, QP_WAVES_PER_EU))) void k_qp_ipm(const smpc_problem_desc* __restrict__ D, int B, int N,
                                                const double* __restrict__ x0, const double* __restrict__ xg,
                                                const double* __restrict__ ug, const double* __restrict__ pp,
                                                const double* __restrict__ lo_st, const double* __restrict__ hi_st,
                                                const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
                                                double* __restrict__ x_out, double* __restrict__ u_out,
-                                               int32_t* __restrict__ status, int32_t* __restrict__ qp_iter) {
+                                               int32_t* __restrict__ status, int32_t* __restrict__ qp_iter,
+                                               const int32_t* __restrict__ order, int32_t* __restrict__ last_iter) {
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, WS = NX + 1;
     constexpr int MAXR = NX + NQ + SMPC_MAX_ROWS + 1;
     constexpr int NTRI_Z = NZ * (NZ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
     constexpr int REC_MAX = QP_PF * 128;
     constexpr int EV_D = (int)(sizeof(smpc_node_eval) / sizeof(double));
-    const int b = blockIdx.x;
-    if (b >= B) return;
+    if ((int)blockIdx.x >= B) return;
+    // longest-expected-first dispatch: block i takes the instance with the i-th largest iteration count of the previous
+    // call (instances are independent, so the order only changes the makespan, never a result)
+    const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
     const int lane = threadIdx.x;
-    const QpLayout<NQ> Ly(D->n_rows);
-    const int MR = Ly.MR, NRT = Ly.NRT;
+    const QpLayout<NQ> Ly(MRT >= 0 ? MRT : D->n_rows);
+    const int MR = MRT >= 0 ? MRT : Ly.MR;
+    const int NRT = NX + NQ + MR + 1;
     const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;  // first torque row, first collision row, the nn row
     double* ws = ws_all + (size_t)b * Ly.per_instance(N);
     const double dt = D->dt, cB = 0.5 * dt * dt;
@@ -147,16 +153,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // ---- LDS ---------------------------------------------------------------------------------------------------------
     __shared__ __attribute__((aligned(16))) double rec[REC_MAX];   // the current stage record
     constexpr int EV_PAD = EV_D + (EV_D & 1);
-    constexpr int SCR_A = NZ * NZ + NQ * NZ + NX * NX;                 // sH | sTD | sP, also the phase-0 staging area
+    constexpr int SCR_A = 3 * NX * NX;                                  // Hxx | P ping | P pong; also the phase-0 staging area
     constexpr int SCR = SCR_A > EV_PAD ? SCR_A : EV_PAD;
     __shared__ __attribute__((aligned(16))) double scr[SCR];
-    double* const sH = scr;
-    double* const sTD = scr + NZ * NZ;
-    double* const sP = scr + NZ * NZ + NQ * NZ;
+    double* const sHXX = scr;
+    double* const sPa = scr + NX * NX;
+    double* const sPb = scr + 2 * NX * NX;
     double* const sEV = scr;
-    __shared__ double sD[MAXR], sE[MAXR], sGH[NZ], sPV[NX], sPT[NX];
+    __shared__ double sD[MAXR], sE[MAXR], sGH[NZ], sPVa[NX], sPVb[NX], sRho[NQ], sX0[NX];
     __shared__ double sLam[NQ * NQ], sG[NQ * WS];
-    __shared__ double sX[NX], sXN[NX], sRHS[NQ], sU[NQ];
     __shared__ unsigned char triZi[NTRI_Z], triZj[NTRI_Z], triXi[NTRI_X], triXj[NTRI_X];
 
     double* const sT = rec + Ly.oT;
@@ -432,35 +437,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         }
     };
 
-    // backward costate step at stage k: given sGH, sPV (= p_{k+1}), sPB, sW, L in registers; updates sPV and W's w column
-    auto vector_back = [&](int k) {
-        if (lane < NX) sPT[lane] = sPV[lane] + sPB[lane];
-        lds_fence();
-        if (lane < NQ) sG[lane * WS + NX] = sGH[lane] + cB * sPT[lane] + dt * sPT[NQ + lane];  // rho
-        lds_fence();
-        double wv[NQ];
+    // register-resident trial point -> value of row r (lane-dependent), z = [u; x] held by every lane
+    auto sel = [&](const double* v, auto n_tag, int idx) -> double {
+        constexpr int n = decltype(n_tag)::value;
+        double o = v[0];
 #pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            double v = sG[i * WS + NX];
+        for (int c = 1; c < n; c++) o = (idx == c) ? v[c] : o;
+        return o;
+    };
+    using TagNX = std::integral_constant<int, NX>;
+    using TagNZ = std::integral_constant<int, NZ>;
+    using TagNQ = std::integral_constant<int, NQ>;
+    auto row_dot_reg = [&](int r, const double* z) -> double {
+        if (r < rT0) return sel(z + NU, TagNX{}, r);
+        double a = 0.0;
+        if (r < rC0) {
+            const double* t = &sT[(r - rT0) * NZ];
 #pragma unroll
-            for (int t = 0; t < i; t++) v = fma(-Lr[i][t], wv[t], v);
-            wv[i] = v * Linv[i];
+            for (int c = 0; c < NZ; c++) a = fma(t[c], z[c], a);
+        } else if (r < rNN) {
+            const double* g = &sGC[(r - rC0) * NQ];
+#pragma unroll
+            for (int c = 0; c < NQ; c++) a = fma(g[c], z[NU + c], a);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NX; c++) a = fma(sGN[c], z[NU + c], a);
         }
-        if (lane == 0) {
+        return a;
+    };
+    // forward step in registers: u = -L^-T (W x + w), z = [u; x], x <- A x + B u + b   (every lane holds x redundantly)
+    auto roll_out = [&](bool has_u, double* xr, double* zr) {
+        if (has_u) {
+            double rhs[NQ], uk[NQ];
 #pragma unroll
-            for (int i = 0; i < NQ; i++) sW[i * WS + NX] = wv[i];
-        }
-        if (k > 0 && lane < NX) {
-            // p_k = gh_x + A^T pt - W^T w
-            const int i = lane;
-            double v = sGH[NU + i] + (i < NQ ? sPT[i] : dt * sPT[i - NQ] + sPT[i]);
+            for (int i = 0; i < NQ; i++) {
+                double v = sW[i * WS + NX];
 #pragma unroll
-            for (int t = 0; t < NQ; t++) v = fma(-sW[t * WS + i], wv[t], v);
-            sXN[i] = v;
+                for (int jx = 0; jx < NX; jx++) v = fma(sW[i * WS + jx], xr[jx], v);
+                rhs[i] = -v;
+            }
+#pragma unroll
+            for (int i = NQ - 1; i >= 0; i--) {
+                double v = rhs[i];
+#pragma unroll
+                for (int t = i + 1; t < NQ; t++) v = fma(-Lr[t][i], uk[t], v);
+                uk[i] = v * Linv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; i++) zr[i] = uk[i];
+#pragma unroll
+            for (int i = 0; i < NX; i++) zr[NU + i] = xr[i];
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                const double q = xr[i], v = xr[NQ + i];
+                xr[i] = q + dt * v + cB * uk[i] + sB[i];
+                xr[NQ + i] = v + dt * uk[i] + sB[NQ + i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NQ; i++) zr[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; i++) zr[NU + i] = xr[i];
         }
-        lds_fence();
-        if (k > 0 && lane < NX) sPV[lane] = sXN[lane];
-        lds_fence();
     };
 
     // =====================================================================================================================
@@ -468,7 +506,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // =====================================================================================================================
     double R0 = 0.0, mu_acc = 0.0;
     int m_comp = 0;
-    if (lane < NX) sX[lane] = dx0_reg;
+    if (lane < NX) sX0[lane] = dx0_reg;
     prefetch(reinterpret_cast<const double*>(evb), EV_D);
     for (int k = 0; k <= N; k++) {
         commit(sEV, EV_D);
@@ -542,7 +580,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         }
         // z = 0 except the fixed dx_0; z_aff, z+ start defined
         if (lane < NZ) {
-            const double z0 = (k == 0 && lane >= NU) ? sX[lane - NU] : 0.0;
+            const double z0 = (k == 0 && lane >= NU) ? sX0[lane - NU] : 0.0;
             sZ[lane] = z0; sZA[lane] = z0; sZN[lane] = z0;
         }
         for (int el = lane; el < Ly.bH - Ly.bFac; el += 64) rec[Ly.bFac + el] = 0.0;
@@ -585,11 +623,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             r0_loc = fmax(r0_loc, fabs(sGZ[lane] + ct_dot(lane, sE)));
         if (!last && lane < NX) {
             double ax = 0.0;  // dynamics defect of the initial point: next dx is 0
-            if (k == 0) ax = lane < NQ ? sX[lane] + dt * sX[NQ + lane] : sX[lane];
+            if (k == 0) ax = lane < NQ ? sX0[lane] + dt * sX0[NQ + lane] : sX0[lane];
             r0_loc = fmax(r0_loc, fabs(ax + sB[lane]));
         }
         R0 = fmax(R0, wave_max(r0_loc));
         m_comp += (int)wave_sum((double)cnt);
+        {
+            const double bmax = wave_max(lane < NX ? fabs(sB[lane]) : 0.0);
+            if (lane == 0) sSC[3] = bmax > 0.0 ? 1.0 : 0.0;
+            lds_fence();
+        }
         write_back(ws + (size_t)k * Ly.stride, rec, Ly.stride);
         lds_fence();
     }
@@ -606,6 +649,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const double tol = D->qp_tol;
     const int max_iter = D->qp_max_iter;
     bool broke = false;
+    double *Pc = sPa, *Pn = sPb;      // P_{k+1} (in use) / P_k (being built)
+    double *pvc = sPVa, *pvn = sPVb;  // costate vectors, same ping-pong
+    lds_fence();
 
     for (it = 0; it < max_iter; it++) {
         if (mu <= tol && rho_lin * R0 <= tol) { st_code = 0; break; }
@@ -618,12 +664,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             commit(rec, Ly.stride);
             lds_fence();
             if (k > 0) prefetch(ws + (size_t)(k - 1) * Ly.stride, Ly.stride);
-            if (pending) {
-                Dir d{0, 0, 0, 0, 0};
-                if (lane < NRT) d = row_dir(lane, row_dot(lane, sZN), sigmu, corr_w, row_dot(lane, sZA));
-                lds_fence();
-                if (lane < NRT) {
-                    const int r = lane;
+            // -- rows: (apply step) + barrier weights + predictor coefficients; every lane touches only its own row
+            if (lane < NRT) {
+                const int r = lane;
+                if (pending) {
+                    const Dir d = row_dir(r, row_dot(r, sZN), sigmu, corr_w, row_dot(r, sZA));
                     if (sLO[r] > -QP_ABSENT) {
                         sTL[r] += alpha * d.dtl;
                         sLL[r] += alpha * d.dll;
@@ -634,24 +679,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         sLU[r] += alpha * d.dlu;
                     }
                 }
-                if (lane < NZ) sZ[lane] += alpha * (sZN[lane] - sZ[lane]);
-                lds_fence();
-            }
-            if (lane < NRT) {
                 double Dr;
-                sE[lane] = row_coeff(lane, 0.0, 0.0, 0.0, &Dr);
-                sD[lane] = Dr;
-                mu_new += row_comp(lane);
+                sE[r] = row_coeff(r, 0.0, 0.0, 0.0, &Dr);
+                sD[r] = Dr;
+                mu_new += row_comp(r);
+            }
+            if (pending && lane < NZ) sZ[lane] += alpha * (sZN[lane] - sZ[lane]);
+            const bool bflag = !last && sSC[3] != 0.0;
+            if (!last && lane < NX) {
+                double a = 0.0;
+                if (bflag) {
+#pragma unroll
+                    for (int jx = 0; jx < NX; jx++) a = fma(Pc[lane * NX + jx], sB[jx], a);
+                }
+                sPB[lane] = a;
             }
             lds_fence();
-            for (int el = lane; el < NQ * NZ; el += 64) sTD[el] = sT[el] * sD[rT0 + el / NZ];
-            lds_fence();
-            // Hessian (upper triangle, mirrored) and gradient
+            // -- fused assembly: H + C^T D C, with B^T P B / B^T P A folded into the u-rows, gradient, rho
             for (int el = lane; el < NTRI_Z; el += 64) {
                 const int i = triZi[el], j = triZj[el];
                 double a = 0.0;
 #pragma unroll
-                for (int r = 0; r < NQ; r++) a = fma(sTD[r * NZ + i], sT[r * NZ + j], a);
+                for (int r = 0; r < NQ; r++) a = fma(sT[r * NZ + i] * sD[rT0 + r], sT[r * NZ + j], a);
                 if (i >= NU) {  // both in the x block (j >= i)
                     const int ix = i - NU, jx = j - NU;
                     a = fma(sGN[ix] * sD[rNN], sGN[jx], a);
@@ -663,48 +712,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         a += sD[ix];
                         if (ix >= NQ) a += sSC[1];
                     }
-                } else if (i == j) {
-                    a += sSC[0];
-                }
-                sH[i * NZ + j] = a;
-                sH[j * NZ + i] = a;
-            }
-            if (lane < NZ) sGH[lane] = sGZ[lane] + ct_dot(lane, sE);
-            lds_fence();
-            if (last) {
-                for (int el = lane; el < NX * NX; el += 64) sP[el] = sH[(NU + el / NX) * NZ + NU + el % NX];
-                if (lane < NX) sPV[lane] = sGH[NU + lane];
-                lds_fence();
-            } else {
-                // P b, Lambda, G
-                if (lane < NX) {
-                    double a = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NX; j++) a = fma(sP[lane * NX + j], sB[j], a);
-                    sPB[lane] = a;
-                }
-                for (int el = lane; el < NQ * NQ; el += 64) {
-                    const int i = el / NQ, j = el % NQ;
+                    if (last) { Pn[ix * NX + jx] = a; Pn[jx * NX + ix] = a; }
+                    else sHXX[ix * NX + jx] = a;
+                } else if (j < NU) {
+                    if (i == j) a += sSC[0];
                     // B^T P B = c^2 P11 + c dt (P12 + P21) + dt^2 P22
-                    sLam[el] = sH[i * NZ + j] + cB * cB * sP[i * NX + j] +
-                               cB * dt * (sP[i * NX + NQ + j] + sP[(NQ + i) * NX + j]) + dt * dt * sP[(NQ + i) * NX + NQ + j];
-                }
-                for (int el = lane; el < NQ * NX; el += 64) {
-                    const int i = el / NX, j = el % NX;
+                    a += cB * cB * Pc[i * NX + j] + cB * dt * (Pc[i * NX + NQ + j] + Pc[(NQ + i) * NX + j]) +
+                         dt * dt * Pc[(NQ + i) * NX + NQ + j];
+                    sLam[i * NQ + j] = a;
+                    sLam[j * NQ + i] = a;
+                } else {
                     // B^T P A: left block c P11 + dt P21 ; right block dt (c P11 + dt P21) + c P12 + dt P22
-                    double v;
-                    if (j < NQ) v = cB * sP[i * NX + j] + dt * sP[(NQ + i) * NX + j];
+                    const int jx = j - NU;
+                    if (jx < NQ) a += cB * Pc[i * NX + jx] + dt * Pc[(NQ + i) * NX + jx];
                     else {
-                        const int jj = j - NQ;
-                        v = dt * (cB * sP[i * NX + jj] + dt * sP[(NQ + i) * NX + jj]) + cB * sP[i * NX + NQ + jj] +
-                            dt * sP[(NQ + i) * NX + NQ + jj];
+                        const int jj = jx - NQ;
+                        a += dt * (cB * Pc[i * NX + jj] + dt * Pc[(NQ + i) * NX + jj]) + cB * Pc[i * NX + NQ + jj] +
+                             dt * Pc[(NQ + i) * NX + NQ + jj];
                     }
-                    sG[i * WS + j] = sH[i * NZ + NU + j] + v;
+                    sG[i * WS + jx] = a;
                 }
-                lds_fence();
+            }
+            if (lane < NZ) {
+                const double gh = sGZ[lane] + ct_dot(lane, sE);
+                if (last) {
+                    if (lane >= NU) pvn[lane - NU] = gh;
+                } else if (lane < NU) {
+                    // rho = gh_u + B^T (p_{k+1} + P b)
+                    sG[lane * WS + NX] = gh + cB * (pvc[lane] + sPB[lane]) + dt * (pvc[NQ + lane] + sPB[NQ + lane]);
+                } else {
+                    sGH[lane] = gh;
+                }
+            }
+            lds_fence();
+            if (!last) {
                 if (!chol_from_lds(sLam)) broke = true;
-                // W = L^-1 G (one column per lane)
-                if (lane < NX) {
+                // [W | w] = L^-1 [G | rho], one column per lane
+                if (lane <= NX) {
                     double col[NQ];
 #pragma unroll
                     for (int i = 0; i < NQ; i++) {
@@ -719,35 +763,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                     for (int i = 0; i < NQ; i++) {
 #pragma unroll
-                        for (int j = 0; j < NQ; j++) sL[i * NQ + j] = j < i ? Lr[i][j] : (j == i ? Linv[i] : 0.0);
+                        for (int jx = 0; jx < NQ; jx++) sL[i * NQ + jx] = jx < i ? Lr[i][jx] : (jx == i ? Linv[i] : 0.0);
                     }
                 }
                 lds_fence();
-                vector_back(k);
                 if (k > 0) {
-                    // P_k = Hxx + A^T P A - W^T W: upper triangle into the (now free) sTD scratch, then mirrored into sP
+                    // P_k = Hxx + A^T P A - W^T W (upper triangle, mirrored into the other buffer) and p_k
                     for (int el = lane; el < NTRI_X; el += 64) {
                         const int i = triXi[el], j = triXj[el];
-                        double a = sH[(NU + i) * NZ + NU + j];
+                        double a = sHXX[i * NX + j];
                         // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]
-                        if (j < NQ) a += sP[i * NX + j];
-                        else if (i < NQ) a += dt * sP[i * NX + (j - NQ)] + sP[i * NX + j];
+                        if (j < NQ) a += Pc[i * NX + j];
+                        else if (i < NQ) a += dt * Pc[i * NX + (j - NQ)] + Pc[i * NX + j];
                         else {
                             const int ii = i - NQ, jj = j - NQ;
-                            a += dt * dt * sP[ii * NX + jj] + dt * (sP[ii * NX + j] + sP[i * NX + jj]) + sP[i * NX + j];
+                            a += dt * dt * Pc[ii * NX + jj] + dt * (Pc[ii * NX + j] + Pc[i * NX + jj]) + Pc[i * NX + j];
                         }
 #pragma unroll
                         for (int t = 0; t < NQ; t++) a = fma(-sW[t * WS + i], sW[t * WS + j], a);
-                        sTD[el] = a;
+                        Pn[i * NX + j] = a;
+                        Pn[j * NX + i] = a;
                     }
-                    lds_fence();
-                    for (int el = lane; el < NTRI_X; el += 64) {
-                        const int i = triXi[el], j = triXj[el];
-                        const double a = sTD[el];
-                        sP[i * NX + j] = a;
-                        sP[j * NX + i] = a;
+                    if (lane < NX) {
+                        const int i = lane;
+                        // p_k = gh_x + A^T (p_{k+1} + P b) - W^T w
+                        double v = sGH[NU + i] + (i < NQ ? pvc[i] + sPB[i]
+                                                         : dt * (pvc[i - NQ] + sPB[i - NQ]) + pvc[i] + sPB[i]);
+#pragma unroll
+                        for (int t = 0; t < NQ; t++) v = fma(-sW[t * WS + i], sW[t * WS + NX], v);
+                        pvn[i] = v;
                     }
-                    lds_fence();
                 }
             }
             // write back what changed: state + z (if a step was applied) and the factors
@@ -755,7 +800,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             if (pending) write_back(w + Ly.bState, rec + Ly.bState, Ly.bFac - Ly.bState);
             if (!last) write_back(w + Ly.bFac, rec + Ly.bFac, Ly.bH - Ly.bFac);
             lds_fence();
+            if (last || k > 0) {
+                double* t1 = Pc; Pc = Pn; Pn = t1;
+                double* t2 = pvc; pvc = pvn; pvn = t2;
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (wave_max(broke ? 1.0 : 0.0) > 0.0) { st_code = 4; pending = false; break; }
         if (pending) {
             mu = wave_sum(mu_new) * inv_m;
@@ -763,54 +813,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             if (!(mu == mu)) { st_code = 4; break; }
         }
 
-        // ---------------- sweep F1: predictor roll-out, affine step length, centring ---------------------------------------
+        // ---------------- sweep F1: predictor roll-out (state in registers), affine step length, centring ------------------
         double amin = 1e300, S1 = 0.0, S2 = 0.0;
-        if (lane < NX) sX[lane] = dx0_reg;
+        double xr[NX], zr[NZ];
+#pragma unroll
+        for (int i = 0; i < NX; i++) xr[i] = sX0[i];
         prefetch(ws, Ly.nPrefix);
         for (int k = 0; k <= N; k++) {
             commit(rec, Ly.nPrefix);
             lds_fence();
-            if (k < N) prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix);
-            if (k < N) {
-                load_L_regs();
-                if (lane < NQ) {
-                    double v = sW[lane * WS + NX];
-#pragma unroll
-                    for (int j = 0; j < NX; j++) v = fma(sW[lane * WS + j], sX[j], v);
-                    sRHS[lane] = -v;
-                }
-                lds_fence();
-                double uk[NQ];
-#pragma unroll
-                for (int i = NQ - 1; i >= 0; i--) {
-                    double v = sRHS[i];
-#pragma unroll
-                    for (int t = i + 1; t < NQ; t++) v = fma(-Lr[t][i], uk[t], v);
-                    uk[i] = v * Linv[i];
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int i = 0; i < NQ; i++) { sZA[i] = uk[i]; sU[i] = uk[i]; }
-                }
-                if (lane < NX) sZA[NU + lane] = sX[lane];
-                lds_fence();
-                if (lane < NX) {
-                    const int i = lane < NQ ? lane : lane - NQ;
-                    const double bk = sB[lane];
-                    sXN[lane] = lane < NQ ? sX[i] + dt * sX[NQ + i] + cB * sU[i] + bk : sX[NQ + i] + dt * sU[i] + bk;
-                }
-            } else {
-                if (lane < NZ) sZA[lane] = lane >= NU ? sX[lane - NU] : 0.0;
-            }
-            lds_fence();
+            if (k < N) { prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix); load_L_regs(); }
+            roll_out(k < N, xr, zr);
             if (lane < NRT) {
-                const Dir d = row_dir(lane, row_dot(lane, sZA), 0.0, 0.0, 0.0);
+                const Dir d = row_dir(lane, row_dot_reg(lane, zr), 0.0, 0.0, 0.0);
                 amin = fmin(amin, row_ratio(lane, d, &S1, &S2));
             }
-            write_back(ws + (size_t)k * Ly.stride + Ly.oZA, sZA, QpLayout<NQ>::NZP);
-            if (k < N && lane < NX) sX[lane] = sXN[lane];
+            if (lane < NZ) ws[(size_t)k * Ly.stride + Ly.oZA + lane] = sel(zr, TagNZ{}, lane);
             lds_fence();
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const double a_aff = fmin(1.0, wave_min(amin));
         S1 = wave_sum(S1);
         S2 = wave_sum(S2);
@@ -833,68 +854,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 sE[lane] = row_coeff(lane, sigmu, corr_w, row_dot(lane, sZA), &Dr);
             }
             lds_fence();
-            if (lane < NZ) sGH[lane] = sGZ[lane] + ct_dot(lane, sE);
-            lds_fence();
-            if (last) {
-                if (lane < NX) sPV[lane] = sGH[NU + lane];
-                lds_fence();
-            } else {
-                load_L_regs();
-                vector_back(k);
-                if (lane < NQ) ws[(size_t)k * Ly.stride + Ly.oW + lane * WS + NX] = sW[lane * WS + NX];
-                lds_fence();
+            if (lane < NZ) {
+                const double gh = sGZ[lane] + ct_dot(lane, sE);
+                if (last) {
+                    if (lane >= NU) pvn[lane - NU] = gh;
+                } else if (lane < NU) {
+                    sRho[lane] = gh + cB * (pvc[lane] + sPB[lane]) + dt * (pvc[NQ + lane] + sPB[NQ + lane]);
+                } else {
+                    sGH[lane] = gh;
+                }
             }
+            lds_fence();
+            if (!last) {
+                load_L_regs();
+                double wv[NQ];
+#pragma unroll
+                for (int i = 0; i < NQ; i++) {
+                    double v = sRho[i];
+#pragma unroll
+                    for (int t = 0; t < i; t++) v = fma(-Lr[i][t], wv[t], v);
+                    wv[i] = v * Linv[i];
+                }
+                if (k > 0 && lane < NX) {
+                    const int i = lane;
+                    double v = sGH[NU + i] + (i < NQ ? pvc[i] + sPB[i] : dt * (pvc[i - NQ] + sPB[i - NQ]) + pvc[i] + sPB[i]);
+#pragma unroll
+                    for (int t = 0; t < NQ; t++) v = fma(-sW[t * WS + i], wv[t], v);
+                    pvn[i] = v;
+                }
+                if (lane < NQ) ws[(size_t)k * Ly.stride + Ly.oW + lane * WS + NX] = sel(wv, TagNQ{}, lane);
+            }
+            lds_fence();
+            if (last || k > 0) { double* t2 = pvc; pvc = pvn; pvn = t2; }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
         // ---------------- sweep F2: corrector roll-out and step length --------------------------------------------------------
         amin = 1e300;
         double S1c = 0.0, S2c = 0.0;
-        if (lane < NX) sX[lane] = dx0_reg;
+#pragma unroll
+        for (int i = 0; i < NX; i++) xr[i] = sX0[i];
         prefetch(ws, Ly.nPrefix);
         for (int k = 0; k <= N; k++) {
             commit(rec, Ly.nPrefix);
             lds_fence();
-            if (k < N) prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix);
-            if (k < N) {
-                load_L_regs();
-                if (lane < NQ) {
-                    double v = sW[lane * WS + NX];
-#pragma unroll
-                    for (int j = 0; j < NX; j++) v = fma(sW[lane * WS + j], sX[j], v);
-                    sRHS[lane] = -v;
-                }
-                lds_fence();
-                double uk[NQ];
-#pragma unroll
-                for (int i = NQ - 1; i >= 0; i--) {
-                    double v = sRHS[i];
-#pragma unroll
-                    for (int t = i + 1; t < NQ; t++) v = fma(-Lr[t][i], uk[t], v);
-                    uk[i] = v * Linv[i];
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int i = 0; i < NQ; i++) { sZN[i] = uk[i]; sU[i] = uk[i]; }
-                }
-                if (lane < NX) sZN[NU + lane] = sX[lane];
-                lds_fence();
-                if (lane < NX) {
-                    const int i = lane < NQ ? lane : lane - NQ;
-                    const double bk = sB[lane];
-                    sXN[lane] = lane < NQ ? sX[i] + dt * sX[NQ + i] + cB * sU[i] + bk : sX[NQ + i] + dt * sU[i] + bk;
-                }
-            } else {
-                if (lane < NZ) sZN[lane] = lane >= NU ? sX[lane - NU] : 0.0;
-            }
-            lds_fence();
+            if (k < N) { prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix); load_L_regs(); }
+            roll_out(k < N, xr, zr);
             if (lane < NRT) {
-                const Dir d = row_dir(lane, row_dot(lane, sZN), sigmu, corr_w, row_dot(lane, sZA));
+                const Dir d = row_dir(lane, row_dot_reg(lane, zr), sigmu, corr_w, row_dot(lane, sZA));
                 amin = fmin(amin, row_ratio(lane, d, &S1c, &S2c));
             }
-            write_back(ws + (size_t)k * Ly.stride + Ly.oZN, sZN, QpLayout<NQ>::NZP);
-            if (k < N && lane < NX) sX[lane] = sXN[lane];
+            if (lane < NZ) ws[(size_t)k * Ly.stride + Ly.oZN + lane] = sel(zr, TagNZ{}, lane);
             lds_fence();
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         alpha = fmin(1.0, QP_FTB * wave_min(amin));
         if (!(alpha == alpha)) { st_code = 4; break; }
         if (alpha < QP_ALPHA_MIN) { st_code = 3; break; }
@@ -932,6 +945,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         if (any_bad && stc == SMPC_STATUS_SUCCESS) stc = SMPC_STATUS_NAN;
         status[b] = stc;
         if (qp_iter) qp_iter[b] = it;
+        if (last_iter) last_iter[b] = it;
+    }
+}
+
+
+// order[] = instance indices sorted by decreasing previous iteration count (counting sort, one block)
+__global__ __launch_bounds__(1024) void k_order_by_iters(int B, const int32_t* __restrict__ last_iter, int32_t* __restrict__ order) {
+    __shared__ int hist[256], offs[256];
+    const int t = threadIdx.x;
+    if (t < 256) hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) atomicAdd(&hist[min(max(last_iter[i], 0), 255)], 1);
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int v = 255; v >= 0; v--) { offs[v] = acc; acc += hist[v]; }
+    }
+    __syncthreads();
+    for (int i = t; i < B; i += 1024) {
+        const int v = min(max(last_iter[i], 0), 255);
+        order[atomicAdd(&offs[v], 1)] = i;
     }
 }
 
