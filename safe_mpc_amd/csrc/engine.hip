@@ -288,6 +288,16 @@ int smpc_create(const smpc_problem_desc* desc, int device, smpc_handle** out) {
         if (row.kind < 0 || row.kind > SMPC_ROW_COORD || row.pa < 0 || row.pa >= desc->n_points)
             return fail(nullptr, SMPC_EINVAL, "row %d malformed", r);
     }
+    {
+        size_t stride = 0, cap = 0;
+        switch (desc->nq) {
+        case 5: stride = QpLayout<5>(desc->n_rows).stride; cap = QpPf<5>::value * 128; break;
+        case 6: stride = QpLayout<6>(desc->n_rows).stride; cap = QpPf<6>::value * 128; break;
+        default: stride = QpLayout<7>(desc->n_rows).stride; cap = QpPf<7>::value * 128; break;
+        }
+        if (stride > cap || sizeof(smpc_node_eval) / sizeof(double) > cap)
+            return fail(nullptr, SMPC_EINVAL, "stage record of %zu doubles exceeds the kernel's staging buffer (%zu)", stride, cap);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, SMPC_EHIP, "no HIP device visible: the engine has no CPU fallback");

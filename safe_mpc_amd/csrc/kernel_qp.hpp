@@ -122,7 +122,8 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 #ifndef QP_WAVES_PER_EU
 #define QP_WAVES_PER_EU 2
 #endif
-constexpr int QP_PF = 5;  // 16-byte prefetch registers per lane: 5 * 64 * 2 = 640 doubles >= any record
+// 16-byte prefetch registers per lane: QP_PF<NQ> * 64 * 2 doubles must hold the largest record (checked in smpc_create)
+template <int NQ> struct QpPf { static constexpr int value = NQ <= 6 ? 5 : 7; };
 
 template <int NQ, int MRT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER_EU, QP_WAVES_PER_EU))) void k_qp_ipm(const smpc_problem_desc* __restrict__ D, int B, int N,
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, WS = NX + 1;
     constexpr int MAXR = NX + NQ + SMPC_MAX_ROWS + 1;
     constexpr int NTRI_Z = NZ * (NZ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
+    constexpr int QP_PF = QpPf<NQ>::value;
     constexpr int REC_MAX = QP_PF * 128;
     constexpr int EV_D = (int)(sizeof(smpc_node_eval) / sizeof(double));
     if ((int)blockIdx.x >= B) return;

@@ -86,3 +86,16 @@ def z1_naive():
 @pytest.fixture(scope='session')
 def z1_st():
     return make_problem('st')
+
+
+def make_problem_fr7(controller='constraint_everywhere', cost='ext', N=40):
+    """BASELINE config 4: 7-DoF Franka-class arm (config_fr7.yaml), sphere obstacle + floor, NN row on every node."""
+    from safe_mpc_amd.parser import Parameters
+    from safe_mpc_amd.problem import OcpProblem
+    from safe_mpc_amd.safe_set import SafeSetNet
+    par = Parameters({}, 'fr7', filename=os.path.join(ROOT, 'config_fr7.yaml'))
+    par.N = N
+    prob = OcpProblem(par, controller, cost, N=N)
+    net = SafeSetNet.from_params(par, prob.x_min, prob.x_max)
+    prob.set_normalisation(net.mean, net.std)
+    return par, prob, net
