@@ -182,6 +182,11 @@ int smpc_set_horizon(smpc_handle* h, int N);
  * shared by all instances, or NULL to restore the descriptor's bounds. */
 int smpc_set_stage_bounds(smpc_handle* h, const double* lo, const double* hi);
 
+/* Per-instance variant for RealReceding's state tube (controller.py:530-536: node r of instance b is boxed to
+ * x_guess[b][r+1] +- 1e-3 with its own r): lo/hi are [B][N+1][nx]; they apply to the next smpc_solve_batch calls with the
+ * same B until cleared with lo = hi = NULL.  Pointers follow on_device like smpc_solve_batch; the handle keeps a copy. */
+int smpc_set_instance_bounds(smpc_handle* h, int B, const double* lo, const double* hi, int on_device);
+
 /* ---- the hot path --------------------------------------------------------------------------------------------- */
 /* One SQP-RTI solve of B independent OCPs: replaces reset / constraints_set(0,lbx|ubx,x0) / set(i,x|u|p) / solve /
  * get(i,x|u) of controller.py:141-164 for B instances in one call.

@@ -92,6 +92,14 @@ class Oracle:
             assert lo.shape == (self.N + 1, self.nx)
             self.L.orc_set_stage_bounds(self.h, _p(lo), _p(hi))
 
+    def set_instance_bounds(self, lo=None, hi=None):
+        if lo is None:
+            self.L.orc_set_instance_bounds(self.h, 0, None, None)
+            return
+        lo, hi = _f64(lo), _f64(hi)
+        assert lo.shape[1:] == (self.N + 1, self.nx)
+        self.L.orc_set_instance_bounds(self.h, lo.shape[0], _p(lo), _p(hi))
+
     # -- components ---------------------------------------------------------------------------------------------------
     def rnea(self, q, qd, qdd):
         q, qd, qdd = _f64(q), _f64(qd), _f64(qdd)

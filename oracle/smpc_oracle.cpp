@@ -920,6 +920,8 @@ struct Oracle {
     Mlp net;
     int N;
     std::vector<double> lo_st, hi_st;  // [N+1][nx]
+    std::vector<double> lo_b, hi_b;    // [B][N+1][nx] per-instance bounds (RealReceding), empty = none
+    int inst_B = 0;
     void reset_bounds() {
         int nx = 2 * D.nq;
         lo_st.assign((size_t)(N + 1) * nx, 0.0);
@@ -964,6 +966,15 @@ int orc_set_horizon(void* h, int N) {
     if (N < 1 || N > SMPC_MAX_N) return SMPC_EINVAL;
     o->N = N;
     o->reset_bounds();
+    return 0;
+}
+int orc_set_instance_bounds(void* h, int B, const double* lo, const double* hi) {
+    Oracle* o = (Oracle*)h;
+    if (!lo || !hi) { o->inst_B = 0; return 0; }
+    size_t n = (size_t)B * (o->N + 1) * 2 * o->D.nq;
+    o->lo_b.assign(lo, lo + n);
+    o->hi_b.assign(hi, hi + n);
+    o->inst_B = B;
     return 0;
 }
 int orc_set_stage_bounds(void* h, const double* lo, const double* hi) {
@@ -1046,7 +1057,10 @@ int orc_solve_batch(void* h, int B, const double* x0, const double* xg, const do
                       pb + (size_t)k * SMPC_NP, &ev[k]);
         std::vector<Stage> S(N + 1);
         double dx0[MAXX];
-        build_qp(D, N, o->lo_st.data(), o->hi_st.data(), ev, x0 + (size_t)b * nx, xb, ub, pb, S, dx0);
+        const size_t boff = (size_t)b * (N + 1) * nx;
+        const double* blo = o->inst_B == B ? o->lo_b.data() + boff : o->lo_st.data();
+        const double* bhi = o->inst_B == B ? o->hi_b.data() + boff : o->hi_st.data();
+        build_qp(D, N, blo, bhi, ev, x0 + (size_t)b * nx, xb, ub, pb, S, dx0);
         int it = 0;
         double res[2] = {0, 0};
         int qs = qp_ipm(S, N, nx, nu, D.dt, dx0, qo, &it, res);

@@ -269,6 +269,28 @@ class RecedingController(STWAController):
         return self._post_solve(x, status, u_abort)
 
 
+class RealReceding(RecedingController):
+    """controller.py:504-565: hard terminal safe set; instead of a running safe-set row, node r of each instance is boxed to
+    the previously planned state x_guess[r+1] +- 1e-3 (per-instance stage bounds in the engine).  No guessCorrection."""
+    cont_name = 'real_receding'
+    TUBE = 1e-3
+
+    def step(self, x):
+        pr = self.problem
+        lo = np.broadcast_to(pr.x_min, (self.B, self.N + 1, self.nx)).copy()      # other nodes: the model bounds (:534-536)
+        hi = np.broadcast_to(pr.x_max, (self.B, self.N + 1, self.nx)).copy()
+        lo[:, self.N], hi[:, self.N] = pr.lbx_e, pr.ubx_e                         # terminal node keeps lbx_e / ubx_e
+        rows = np.where(self.r < self.N)[0]
+        if rows.size:
+            r = self.r[rows]
+            centre = self.x_guess[rows, r + 1]
+            lo[rows, r], hi[rows, r] = centre - self.TUBE, centre + self.TUBE
+        self.ocp_solver.set_instance_bounds(lo, hi)
+        u_abort = self.u_guess[:, 0].copy()
+        status = self.solve(x)
+        return self._post_solve(x, status, u_abort)
+
+
 class ControllerSafeSetEverywhere(STController):
     cont_name = 'constraint_everywhere'
 
@@ -291,14 +313,12 @@ class SafeBackupController(AbstractController):
 
 
 CONTROLLERS = {'naive': NaiveController, 'zerovel': TerminalZeroVelocity, 'st': STController, 'stwa': STWAController,
-               'htwa': HTWAController, 'receding': RecedingController,
+               'htwa': HTWAController, 'receding': RecedingController, 'real_receding': RealReceding,
                'constraint_everywhere': ControllerSafeSetEverywhere}
 
 
 def get_controller(cont_name, params, batch, **kw):
-    """utils.py:64-75.  'real_receding' needs per-instance stage bounds (controller.py:530-536) -- not in this round."""
-    if cont_name == 'real_receding':
-        raise NotImplementedError('real_receding (per-instance state tubes) is not part of round 1')
+    """utils.py:64-75"""
     if cont_name not in CONTROLLERS:
         raise ValueError(f'Controller {cont_name} not available')
     return CONTROLLERS[cont_name](params, batch, **kw)

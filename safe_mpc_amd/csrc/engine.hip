@@ -27,6 +27,8 @@ struct smpc_handle {
     hipStream_t stream = nullptr;
     smpc_problem_desc* d_desc = nullptr;
     double *d_lo = nullptr, *d_hi = nullptr;  // [N+1][nx] stage bounds
+    double *d_lo_b = nullptr, *d_hi_b = nullptr;  // [B][N+1][nx] per-instance bounds (RealReceding), valid for inst_B
+    int inst_B = 0;
     // network
     int nlayers = 0;
     int dims[SMPC_MAX_LAYERS + 1] = {0};
@@ -239,17 +241,21 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev))) return rc;
     // fast path: the row count of the reference's default geometry (6 capsule pairs, config.yaml:205-216) is a
     // compile-time constant of the kernel; any other geometry takes the runtime-row-count instantiation
+    const bool per_inst = h->inst_B == B;
+    const double* blo = per_inst ? h->d_lo_b : h->d_lo;
+    const double* bhi = per_inst ? h->d_hi_b : h->d_hi;
+    const long bstride = per_inst ? (long)(h->N + 1) * 2 * h->desc.nq : 0L;
     const int32_t* order = nullptr;
     if (h->order_B == B && B > 1) {
         hipLaunchKernelGGL(k_order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->d_last_it, h->d_order);
         order = h->d_order;
     }
     if (h->desc.n_rows == 6)
-        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, h->d_lo,
-                           h->d_hi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it);
+        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
+                           bhi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it, bstride);
     else
-        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, h->d_lo,
-                           h->d_hi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it);
+        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
+                           bhi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it, bstride);
     h->order_B = B;
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream));
@@ -331,7 +337,7 @@ void smpc_destroy(smpc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_desc, h->d_lo, h->d_hi, h->d_ev, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
+    void* ptrs[] = {h->d_desc, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
                     h->d_st, h->d_it, h->d_S, h->d_y, h->d_GS, h->d_dA, h->d_dB, h->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < SMPC_MAX_LAYERS; l++) {
@@ -390,6 +396,7 @@ int smpc_set_horizon(smpc_handle* h, int N) {
     if (N < 1 || N > SMPC_MAX_N) return fail(h, SMPC_EINVAL, "N=%d outside 1..%d", N, SMPC_MAX_N);
     (void)hipSetDevice(h->device);
     h->N = N;
+    h->inst_B = 0;
     h->ws_bytes = 0;  // workspace layout depends on N
     return upload_bounds(h, nullptr, nullptr);
 }
@@ -399,6 +406,25 @@ int smpc_set_stage_bounds(smpc_handle* h, const double* lo, const double* hi) {
     if ((lo == nullptr) != (hi == nullptr)) return fail(h, SMPC_EINVAL, "lo and hi must both be given or both be NULL");
     (void)hipSetDevice(h->device);
     return upload_bounds(h, lo, hi);
+}
+
+int smpc_set_instance_bounds(smpc_handle* h, int B, const double* lo, const double* hi, int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if ((lo == nullptr) != (hi == nullptr)) return fail(h, SMPC_EINVAL, "lo and hi must both be given or both be NULL");
+    (void)hipSetDevice(h->device);
+    if (!lo) { h->inst_B = 0; return SMPC_OK; }
+    if (B <= 0) return fail(h, SMPC_EINVAL, "bad batch size");
+    const size_t n = (size_t)B * (h->N + 1) * 2 * h->desc.nq;
+    int rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = dev_alloc(h, &h->d_lo_b, n))) return rc;
+    if ((rc = dev_alloc(h, &h->d_hi_b, n))) return rc;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPCHK(h, hipMemcpyAsync(h->d_lo_b, lo, n * sizeof(double), kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_hi_b, hi, n * sizeof(double), kind, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->inst_B = B;
+    return SMPC_OK;
 }
 
 int smpc_solve_batch(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,

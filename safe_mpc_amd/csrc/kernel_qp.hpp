@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                                                const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
                                                double* __restrict__ x_out, double* __restrict__ u_out,
                                                int32_t* __restrict__ status, int32_t* __restrict__ qp_iter,
-                                               const int32_t* __restrict__ order, int32_t* __restrict__ last_iter) {
+                                               const int32_t* __restrict__ order, int32_t* __restrict__ last_iter, long bnd_stride) {
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, WS = NX + 1;
     constexpr int MAXR = NX + NQ + SMPC_MAX_ROWS + 1;
     constexpr int NTRI_Z = NZ * (NZ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
@@ -564,7 +564,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             const int r = lane;
             double lo = -QP_ABSENT, hi = QP_ABSENT;
             if (r < rT0) {
-                const double l = lo_st[(size_t)k * NX + r], h = hi_st[(size_t)k * NX + r];
+                const size_t bo = (size_t)b * bnd_stride + (size_t)k * NX + r;  // bnd_stride = 0: bounds shared by all instances
+                const double l = lo_st[bo], h = hi_st[bo];
                 if (k >= 1 && fabs(l) < SMPC_INF) lo = l - xk[r];
                 if (k >= 1 && fabs(h) < SMPC_INF) hi = h - xk[r];
             } else if (r < rC0) {
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         double mu_new = 0.0;
         prefetch(ws + (size_t)N * Ly.stride, Ly.stride);
         for (int k = N; k >= 0; k--) {
+            asm volatile("; QPMARK B1_BEGIN");
             const bool last = (k == N);
             commit(rec, Ly.stride);
             lds_fence();
@@ -806,6 +808,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 double* t1 = Pc; Pc = Pn; Pn = t1;
                 double* t2 = pvc; pvc = pvn; pvn = t2;
             }
+            asm volatile("; QPMARK B1_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (wave_max(broke ? 1.0 : 0.0) > 0.0) { st_code = 4; pending = false; break; }
@@ -822,6 +825,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         for (int i = 0; i < NX; i++) xr[i] = sX0[i];
         prefetch(ws, Ly.nPrefix);
         for (int k = 0; k <= N; k++) {
+            asm volatile("; QPMARK F1_BEGIN");
             commit(rec, Ly.nPrefix);
             lds_fence();
             if (k < N) { prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix); load_L_regs(); }
@@ -832,6 +836,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             }
             if (lane < NZ) ws[(size_t)k * Ly.stride + Ly.oZA + lane] = sel(zr, TagNZ{}, lane);
             lds_fence();
+            asm volatile("; QPMARK F1_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const double a_aff = fmin(1.0, wave_min(amin));
@@ -847,6 +852,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         // ---------------- sweep B2: corrector gradient and costate recursion with the stored factors ------------------------
         prefetch(ws + (size_t)N * Ly.stride, Ly.nPrefix);
         for (int k = N; k >= 0; k--) {
+            asm volatile("; QPMARK B2_BEGIN");
             const bool last = (k == N);
             commit(rec, Ly.nPrefix);
             lds_fence();
@@ -888,6 +894,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             }
             lds_fence();
             if (last || k > 0) { double* t2 = pvc; pvc = pvn; pvn = t2; }
+            asm volatile("; QPMARK B2_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
@@ -898,6 +905,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         for (int i = 0; i < NX; i++) xr[i] = sX0[i];
         prefetch(ws, Ly.nPrefix);
         for (int k = 0; k <= N; k++) {
+            asm volatile("; QPMARK F2_BEGIN");
             commit(rec, Ly.nPrefix);
             lds_fence();
             if (k < N) { prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix); load_L_regs(); }
@@ -908,6 +916,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             }
             if (lane < NZ) ws[(size_t)k * Ly.stride + Ly.oZN + lane] = sel(zr, TagNZ{}, lane);
             lds_fence();
+            asm volatile("; QPMARK F2_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         alpha = fmin(1.0, QP_FTB * wave_min(amin));

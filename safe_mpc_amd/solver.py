@@ -75,6 +75,15 @@ class BatchedOcpSolver:
         assert lo.shape == (self.N + 1, self.nx) and hi.shape == lo.shape
         self._chk(self.L.smpc_set_stage_bounds(self.h, lo.ctypes.data, hi.ctypes.data))
 
+    def set_instance_bounds(self, lo=None, hi=None):
+        """Per-instance stage bounds [B, N+1, nx] (RealReceding's state tube, controller.py:530-536); None clears."""
+        if lo is None:
+            self._chk(self.L.smpc_set_instance_bounds(self.h, 0, None, None, 0))
+            return
+        B = lo.shape[0]
+        ptrs, dev, keep = self._prep([lo, hi], [(B, self.N + 1, self.nx)] * 2)
+        self._chk(self.L.smpc_set_instance_bounds(self.h, B, ptrs[0], ptrs[1], dev))
+
     def sync(self):
         self._chk(self.L.smpc_sync(self.h))
 

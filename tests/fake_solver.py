@@ -19,6 +19,9 @@ class OracleSolver:
     def set_stage_bounds(self, lo=None, hi=None):
         self.o.set_stage_bounds(lo, hi)
 
+    def set_instance_bounds(self, lo=None, hi=None):
+        self.o.set_instance_bounds(lo, hi)
+
     def solve(self, x0, xg, ug, p, out=None):
         x, u, st, it = self.o.solve_batch(x0, xg, ug, p)
         if self.scripted_status:

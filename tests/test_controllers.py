@@ -94,7 +94,7 @@ def test_receding_index_automaton():
     assert seen_flags[1][0, 4] == 1 and np.all(seen_flags[1][0, 1:4] == -1)
 
 
-@pytest.mark.parametrize('name', ['naive', 'st', 'htwa', 'receding', 'constraint_everywhere'])
+@pytest.mark.parametrize('name', ['naive', 'st', 'htwa', 'receding', 'real_receding', 'constraint_everywhere'])
 def test_closed_loop_on_cpu_double(name):
     """A few closed-loop steps of every registered policy: finite controls, states stay inside the widened box."""
     par, c, x0 = _make(name, B=3, N=8)
@@ -108,6 +108,26 @@ def test_closed_loop_on_cpu_double(name):
 
 
 def test_get_controller_registry():
-    assert set(C.CONTROLLERS) == {'naive', 'zerovel', 'st', 'stwa', 'htwa', 'receding', 'constraint_everywhere'}
+    assert set(C.CONTROLLERS) == {'naive', 'zerovel', 'st', 'stwa', 'htwa', 'receding', 'real_receding',
+                                  'constraint_everywhere'}
     with pytest.raises(ValueError):
         C.get_controller('nope', None, 1)
+
+
+def test_real_receding_tube_bounds_reach_the_solver():
+    """controller.py:530-536: node r of every instance is boxed to x_guess[r+1] +- 1e-3; the other nodes get the model box."""
+    par, c, x0 = _make('real_receding', B=3, N=6)
+    seen = {}
+    orig = c.ocp_solver.set_instance_bounds
+    c.ocp_solver.set_instance_bounds = lambda lo, hi: (seen.update(lo=lo.copy(), hi=hi.copy()), orig(lo, hi))[1]
+    c.checkSafeConstraints = lambda x: np.zeros((3, 7), bool)
+    c.step(x0)                                   # r = N: no tube yet
+    assert np.allclose(seen['lo'][:, 1:6], c.problem.x_min) and np.allclose(seen['hi'][:, 1:6], c.problem.x_max)
+    assert c.r.tolist() == [5, 5, 5]
+    guess_before = c.x_guess.copy()
+    u, ab = c.step(c.x_guess[:, 0].copy())       # r = 5 < N: node 5 boxed around x_guess[6]
+    assert np.allclose(seen['lo'][:, 5], guess_before[:, 6] - 1e-3) and np.allclose(seen['hi'][:, 5], guess_before[:, 6] + 1e-3)
+    # the solution honours the tube (status 0 instances)
+    ok = c.last_status == 0
+    assert ok.any()
+    assert np.all(np.abs(c.x_temp[ok, 5] - guess_before[ok, 6]) <= 1e-3 + 1e-6)

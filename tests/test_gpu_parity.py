@@ -206,3 +206,27 @@ def test_policy_layer_and_scripts_on_engine(tmp_path):
         both = ~np.isnan(cpu['x']).any(axis=(1, 2))
         assert both.sum() >= 8
         assert np.nanmax(np.abs(gpu['x'][both] - cpu['x'][both])) < 1e-4
+
+
+def test_instance_bounds_parity():
+    """smpc_set_instance_bounds: per-instance state tubes (RealReceding) agree with the oracle and clear again."""
+    par, prob, net = make_problem('real_receding', N=10)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    B = 16
+    x0 = sample_instances(prob, B, seed=12, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    xa0, ua0, sa0, _ = s.solve(x0, xg, ug, p)
+    lo = np.broadcast_to(prob.x_min, (B, 11, 12)).copy(); hi = np.broadcast_to(prob.x_max, (B, 11, 12)).copy()
+    r = 2 + np.arange(B) % 7
+    lo[np.arange(B), r] = xa0[np.arange(B), r] - 1e-3
+    hi[np.arange(B), r] = xa0[np.arange(B), r] + 1e-3
+    s.set_instance_bounds(lo, hi); o.set_instance_bounds(lo, hi)
+    xa, ua, sa, ia = s.solve(x0, xg, ug, p)
+    xb, ub, sb, ib = o.solve_batch(x0, xg, ug, p)
+    assert np.array_equal(sa, sb)
+    ok = sb == 0
+    assert ok.sum() >= B - 2 and np.abs(ua[ok] - ub[ok]).max() < 1e-4 * (1 + np.abs(ub[ok]).max())
+    assert np.all(np.abs(xa[ok, r[ok]] - xa0[ok, r[ok]]) <= 1e-3 + 1e-6)
+    s.set_instance_bounds(None, None)
+    xa1, ua1, _, _ = s.solve(x0, xg, ug, p)
+    assert np.array_equal(ua1, ua0)
