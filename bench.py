@@ -123,8 +123,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('SMPC_FORCE_DIST') == '1'      # the env knob exercises the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from safe_mpc_amd.sharding import gather_to_root, shard_range
@@ -174,10 +176,10 @@ def main():
                 sb.x_sim, _ = sv.plant_step(sb.x_sim, u_apply)                        # env_model.py:192-206 (nominal plant)
                 sb.iters.add_(it.sum())
                 sb.fails.add_((st != 0).sum())
-                if world > 1:
+                if use_dist:
                     sb.payload[:, :nu] = u_apply
                     sb.payload[:, nu] = st.to(torch.float64)
-        if world > 1:                                                                 # the single result gather
+        if use_dist:                                                                  # the single result gather
             for sb in subs:
                 sb.stream.synchronize()
             off = 0
@@ -190,7 +192,7 @@ def main():
         for sb in subs:
             sb.solver.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,7 +208,7 @@ def main():
         step(first=(args.warmup == 0 and i == 0))
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -260,7 +262,7 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

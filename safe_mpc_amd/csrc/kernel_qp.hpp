@@ -919,7 +919,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             asm volatile("; QPMARK F2_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        alpha = fmin(1.0, QP_FTB * wave_min(amin));
+        // fraction to the boundary (see oracle): 0.995, approaching 1 with the complementarity (cap 0.9999) when the step is
+        // within 1% of the full Newton step; an earlier-blocked step keeps the classical margin to stay centred
+        const double a_max = wave_min(amin);
+        const double tau_k = a_max >= 0.99 ? fmin(0.9999, fmax(QP_FTB, 1.0 - mu)) : QP_FTB;
+        alpha = fmin(1.0, tau_k * a_max);
         if (!(alpha == alpha)) { st_code = 4; break; }
         if (alpha < QP_ALPHA_MIN) { st_code = 3; break; }
         pending = true;
