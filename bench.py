@@ -237,8 +237,14 @@ def main():
         acc /= probes
         alg = algorithmic_bytes(prob.nq, N) * B
         ach = alg / acc[2] / 1e9
+        # HBM bytes per launch from the committed PMC passes of the same kernel / workload (profiles/, scripts/pmc_traffic.py);
+        # counters cannot be read from inside this process
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(tf) and B == B_PER_GPU:
+            traffic = json.load(open(tf))['traffic_bytes_per_launch']
         roof = {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
                 'kernel_ms': {'linearise': acc[0] * 1e3, 'mlp': acc[1] * 1e3, 'qp': acc[2] * 1e3, 'solve_total': acc[3] * 1e3},
                 'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={B}, alone on the GPU'}
 
