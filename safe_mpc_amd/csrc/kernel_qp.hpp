@@ -844,7 +844,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         S2 = wave_sum(S2);
         const double mu_aff = (mu * (double)m_comp + a_aff * S1 + a_aff * a_aff * S2) * inv_m;
         double sigma = mu_aff / mu;
-        sigma = sigma * sigma * sigma;
+        sigma = fmin(sigma * sigma * sigma, 0.3);  // centring cap (see oracle): halves the iteration tail
         sigmu = sigma * mu;
         // safeguard against Mehrotra cycling (see oracle): damp the second-order term when the affine step is blocked early
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
