@@ -11,7 +11,8 @@ import subprocess
 from .problem import Joint, NodeEval, ProblemDesc
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
-LIB_PATH = os.path.join(_CSRC, 'libsmpc_hip.so')
+# SMPC_HIP_LIB selects another build of the SAME engine (diagnostic builds of scripts/qp_phase_profile.py)
+LIB_PATH = os.environ.get('SMPC_HIP_LIB') or os.path.join(_CSRC, 'libsmpc_hip.so')
 
 SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error', 'smpc_set_mlp', 'smpc_set_horizon',
            'smpc_set_stage_bounds', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',

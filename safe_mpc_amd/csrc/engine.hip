@@ -251,10 +251,10 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         order = h->d_order;
     }
     if (h->desc.n_rows == 6)
-        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
+        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
                            bhi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it, bstride);
     else
-        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3(B), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
+        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
                            bhi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it, bstride);
     h->order_B = B;
     HIPCHK(h, hipGetLastError());
@@ -297,9 +297,9 @@ int smpc_create(const smpc_problem_desc* desc, int device, smpc_handle** out) {
     {
         size_t stride = 0, cap = 0;
         switch (desc->nq) {
-        case 5: stride = QpLayout<5>(desc->n_rows).stride; cap = QpPf<5>::value * 128; break;
-        case 6: stride = QpLayout<6>(desc->n_rows).stride; cap = QpPf<6>::value * 128; break;
-        default: stride = QpLayout<7>(desc->n_rows).stride; cap = QpPf<7>::value * 128; break;
+        case 5: stride = QpLayout<5>(desc->n_rows).stride; cap = QpPf<5>::value * 64; break;
+        case 6: stride = QpLayout<6>(desc->n_rows).stride; cap = QpPf<6>::value * 64; break;
+        default: stride = QpLayout<7>(desc->n_rows).stride; cap = QpPf<7>::value * 64; break;
         }
         if (stride > cap || sizeof(smpc_node_eval) / sizeof(double) > cap)
             return fail(nullptr, SMPC_EINVAL, "stage record of %zu doubles exceeds the kernel's staging buffer (%zu)", stride, cap);
@@ -675,3 +675,13 @@ int smpc_get_timing(smpc_handle* h, float* ms4) {
 }
 
 }  // extern "C"
+
+#ifdef QP_PROFILE
+// diagnostic builds only (not part of include/smpc.h): per-phase shader-clock sums of k_qp_ipm since the last call
+extern "C" int smpc_debug_qp_profile(unsigned long long* out16) {
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(smpc::g_qp_prof), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smpc::g_qp_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+#endif

@@ -2,7 +2,13 @@
 // method whose Newton systems are factorised by a Riccati recursion (the role HPIPM plays for acados; N4/N5 in SURVEY
 // section 2; options of reference controller.py:97-110, config.yaml:15-21).
 //
-// Mapping: ONE WAVEFRONT PER OCP INSTANCE (block = 64 threads).  The wave walks the horizon four times per IPM iteration
+// Mapping: ONE WAVEFRONT PER PAIR OF OCP INSTANCES (block = 64 threads): lanes 0-31 own one instance, lanes 32-63 another,
+// each with its own LDS region, workspace and iteration state; the two halves never exchange data, so every branch
+// below is half-uniform and the SIMT exec mask does the rest (a half that has converged simply idles until its twin is
+// done; longest-first dispatch pairs instances with similar iteration counts).  Every per-stage phase of the algorithm is
+// at most 32 wide except the two matrix assemblies, so a half-wave per instance nearly halves the instructions issued per
+// instance compared with a full wave (v3, git history) while the LDS footprint per CU is the same (8 waves x 2 x 10 KB).
+// Each half walks the horizon four times per IPM iteration
 //   B1  backward: apply the previous step, barrier weights, H + C^T D C, Riccati factorisation, predictor costate
 //   F1  forward : predictor roll-out, affine step length, centring parameter
 //   B2  backward: corrector gradient, costate recursion with the stored factors
@@ -29,6 +35,7 @@ constexpr double QP_ALPHA_MIN = 1e-12;
 constexpr double QP_ABSENT = 1e300;  // sentinel for a missing bound side inside the workspace
 
 __host__ __device__ inline int qp_even(int n) { return (n + 1) & ~1; }
+constexpr int qp_even_c(int n) { return (n + 1) & ~1; }
 
 // record layout of one stage, in doubles; every block starts on a 16-byte boundary
 template <int NQ> struct QpLayout {
@@ -88,19 +95,19 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ double wave_min(double v) {
+__device__ __forceinline__ double half_min(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    for (int o = 16; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ double wave_max(double v) {
+__device__ __forceinline__ double half_max(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    for (int o = 16; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ double half_sum(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
 // 1/x to (almost) full double precision: hardware seed + two Newton steps
@@ -119,11 +126,19 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
+// diagnostic build (-DQP_PROFILE, scripts/qp_phase_profile.py): per-phase shader-clock sums over all waves
+#ifdef QP_PROFILE
+__device__ unsigned long long g_qp_prof[16];
+#define QPT(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define QPT(i) do { } while (0)
+#endif
+
 #ifndef QP_WAVES_PER_EU
 #define QP_WAVES_PER_EU 2
 #endif
-// 16-byte prefetch registers per lane: QP_PF<NQ> * 64 * 2 doubles must hold the largest record (checked in smpc_create)
-template <int NQ> struct QpPf { static constexpr int value = NQ <= 6 ? 5 : 7; };
+// 16-byte prefetch registers per lane: QpPf<NQ> * 32 lanes * 2 doubles must hold the largest record (checked in smpc_create)
+template <int NQ> struct QpPf { static constexpr int value = NQ <= 6 ? 9 : 13; };
 
 template <int NQ, int MRT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER_EU, QP_WAVES_PER_EU))) void k_qp_ipm(const smpc_problem_desc* __restrict__ D, int B, int N,
@@ -138,13 +153,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int MAXR = NX + NQ + SMPC_MAX_ROWS + 1;
     constexpr int NTRI_Z = NZ * (NZ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
     constexpr int QP_PF = QpPf<NQ>::value;
-    constexpr int REC_MAX = QP_PF * 128;
+    constexpr int REC_MAX = QP_PF * 64;
     constexpr int EV_D = (int)(sizeof(smpc_node_eval) / sizeof(double));
-    if ((int)blockIdx.x >= B) return;
-    // longest-expected-first dispatch: block i takes the instance with the i-th largest iteration count of the previous
+#ifdef QP_PROFILE
+    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
+    const int hl = threadIdx.x & 31, half = threadIdx.x >> 5;
+    const int slot = 2 * (int)blockIdx.x + half;
+    if (slot >= B) return;  // odd batch: the last half-wave has no instance
+    // longest-expected-first dispatch: slot i takes the instance with the i-th largest iteration count of the previous
     // call (instances are independent, so the order only changes the makespan, never a result)
-    const int b = order ? order[blockIdx.x] : (int)blockIdx.x;
-    const int lane = threadIdx.x;
+    const int b = order ? order[slot] : slot;
     const QpLayout<NQ> Ly(MRT >= 0 ? MRT : D->n_rows);
     const int MR = MRT >= 0 ? MRT : Ly.MR;
     const int NRT = NX + NQ + MR + 1;
@@ -153,18 +173,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const double dt = D->dt, cB = 0.5 * dt * dt;
 
     // ---- LDS ---------------------------------------------------------------------------------------------------------
-    __shared__ __attribute__((aligned(16))) double rec[REC_MAX];   // the current stage record
     constexpr int EV_PAD = EV_D + (EV_D & 1);
     constexpr int SCR_A = 3 * NX * NX;                                  // Hxx | P ping | P pong; also the phase-0 staging area
     constexpr int SCR = SCR_A > EV_PAD ? SCR_A : EV_PAD;
-    __shared__ __attribute__((aligned(16))) double scr[SCR];
+    constexpr int MAXR_E = qp_even_c(MRT >= 0 ? NX + NQ + MRT + 1 : MAXR);
+    // one region per half-wave: [record | scratch | D | E | gh | p ping | p pong | rho | dx0 | Lambda | G]
+    constexpr int O_SCR = REC_MAX, O_D = O_SCR + SCR, O_E = O_D + MAXR_E, O_GH = O_E + MAXR_E, O_PVA = O_GH + qp_even_c(NZ),
+                  O_PVB = O_PVA + NX, O_RHO = O_PVB + NX, O_X0 = O_RHO + qp_even_c(NQ), O_LAM = O_X0 + NX,
+                  O_G = O_LAM + qp_even_c(NQ * NQ), HALF_D = O_G + qp_even_c(NQ * WS);
+    __shared__ __attribute__((aligned(16))) double smem[2 * HALF_D];
+    __shared__ unsigned char triZi[NTRI_Z], triZj[NTRI_Z], triXi[NTRI_X], triXj[NTRI_X];
+    double* const rec = smem + half * HALF_D;   // the current stage record
+    double* const scr = rec + O_SCR;
     double* const sHXX = scr;
     double* const sPa = scr + NX * NX;
     double* const sPb = scr + 2 * NX * NX;
     double* const sEV = scr;
-    __shared__ double sD[MAXR], sE[MAXR], sGH[NZ], sPVa[NX], sPVb[NX], sRho[NQ], sX0[NX];
-    __shared__ double sLam[NQ * NQ], sG[NQ * WS];
-    __shared__ unsigned char triZi[NTRI_Z], triZj[NTRI_Z], triXi[NTRI_X], triXj[NTRI_X];
+    double* const sD = rec + O_D;
+    double* const sE = rec + O_E;
+    double* const sGH = rec + O_GH;
+    double* const sPVa = rec + O_PVA;
+    double* const sPVb = rec + O_PVB;
+    double* const sRho = rec + O_RHO;
+    double* const sX0 = rec + O_X0;
+    double* const sLam = rec + O_LAM;
+    double* const sG = rec + O_G;
 
     double* const sT = rec + Ly.oT;
     double* const sGC = rec + Ly.oGC;
@@ -187,13 +220,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sB = rec + Ly.oB;
     double* const sSC = rec + Ly.oSC;
 
-    for (int e = lane; e < NTRI_Z; e += 64) {
+    for (int e = hl; e < NTRI_Z; e += 32) {
         int i = 0, rem = e;
         while (rem >= NZ - i) { rem -= NZ - i; i++; }
         triZi[e] = (unsigned char)i;
         triZj[e] = (unsigned char)(i + rem);
     }
-    for (int e = lane; e < NTRI_X; e += 64) {
+    for (int e = hl; e < NTRI_X; e += 32) {
         int i = 0, rem = e;
         while (rem >= NX - i) { rem -= NX - i; i++; }
         triXi[e] = (unsigned char)i;
@@ -205,7 +238,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const double* pb = pp + (size_t)b * (N + 1) * SMPC_NP;
     const smpc_node_eval* evb = ev + (size_t)b * (N + 1);
 
-    const double dx0_reg = lane < NX ? x0[(size_t)b * NX + lane] - xb[lane] : 0.0;
+    const double dx0_reg = hl < NX ? x0[(size_t)b * NX + hl] - xb[hl] : 0.0;
 
     // ---- record movement ----------------------------------------------------------------------------------------------
     dbl2 pf[QP_PF];
@@ -214,7 +247,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         const int n2 = n >> 1;
 #pragma unroll
         for (int j = 0; j < QP_PF; j++) {
-            const int i = lane + 64 * j;
+            const int i = hl + 32 * j;
             if (i < n2) pf[j] = s2[i];
         }
     };
@@ -223,14 +256,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         const int n2 = n >> 1;
 #pragma unroll
         for (int j = 0; j < QP_PF; j++) {
-            const int i = lane + 64 * j;
+            const int i = hl + 32 * j;
             if (i < n2) d2[i] = pf[j];
         }
     };
     auto write_back = [&](double* dst, const double* src_lds, int n) {  // n even, both 16-byte aligned
         dbl2* d2 = reinterpret_cast<dbl2*>(dst);
         const dbl2* s2 = reinterpret_cast<const dbl2*>(src_lds);
-        for (int i = lane; i < (n >> 1); i += 64) d2[i] = s2[i];
+        for (int i = hl; i < (n >> 1); i += 32) d2[i] = s2[i];
     };
 
     // row product  c_r . z   for the row owned by this lane (z in LDS, layout [u; q; v])
@@ -508,7 +541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // =====================================================================================================================
     double R0 = 0.0, mu_acc = 0.0;
     int m_comp = 0;
-    if (lane < NX) sX0[lane] = dx0_reg;
+    if (hl < NX) sX0[hl] = dx0_reg;
     prefetch(reinterpret_cast<const double*>(evb), EV_D);
     for (int k = 0; k <= N; k++) {
         commit(sEV, EV_D);
@@ -524,44 +557,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         bool nn_on = false;
         if (D->nn_mode != SMPC_NN_NONE && k >= 1 && (D->nn_mode == SMPC_NN_ALL || last)) nn_on = pk[4] > 0.0;
 
-        for (int el = lane; el < NQ * NZ; el += 64) {
+        for (int el = hl; el < NQ * NZ; el += 32) {
             const int r = el / NZ, c = el % NZ;
             double v = 0.0;
             if (!last) v = c < NQ ? e.M[r * NQ + c] : (c < 2 * NQ ? e.dtau_dq[r * NQ + c - NQ] : e.dtau_dv[r * NQ + c - 2 * NQ]);
             sT[el] = v;
         }
-        for (int el = lane; el < MR * NQ; el += 64) sGC[el] = e.row_grad[el];
-        if (lane < NX) sGN[lane] = nn_on ? e.nn_grad[lane] : 0.0;
-        for (int el = lane; el < NQ * NQ; el += 64) {
+        for (int el = hl; el < MR * NQ; el += 32) sGC[el] = e.row_grad[el];
+        if (hl < NX) sGN[hl] = nn_on ? e.nn_grad[hl] : 0.0;
+        for (int el = hl; el < NQ * NQ; el += 32) {
             const int i = el / NQ, j = el % NQ;
             sHQQ[el] = (reach ? cs * e.cost_hess_qq[el] : 0.0) + (i == j ? lm : 0.0);
         }
-        if (lane < NZ) {
+        if (hl < NZ) {
             double g = 0.0;
             if (reach) {
-                if (lane < NU) g = last ? 0.0 : cs * 2.0 * D->R * ub[(size_t)k * NU + lane];
-                else if (lane < NU + NQ) g = cs * e.cost_grad_q[lane - NU];
+                if (hl < NU) g = last ? 0.0 : cs * 2.0 * D->R * ub[(size_t)k * NU + hl];
+                else if (hl < NU + NQ) g = cs * e.cost_grad_q[hl - NU];
             }
-            sGZ[lane] = g;
+            sGZ[hl] = g;
         }
-        if (lane < NX) {
+        if (hl < NX) {
             double bb = 0.0;
             if (!last) {
                 const double* xn = xk + NX;
-                const int i = lane < NQ ? lane : lane - NQ;
+                const int i = hl < NQ ? hl : hl - NQ;
                 const double uk = ub[(size_t)k * NU + i];
-                bb = lane < NQ ? xk[i] + dt * xk[NQ + i] + cB * uk - xn[i] : xk[NQ + i] + dt * uk - xn[NQ + i];
+                bb = hl < NQ ? xk[i] + dt * xk[NQ + i] + cB * uk - xn[i] : xk[NQ + i] + dt * uk - xn[NQ + i];
             }
-            sB[lane] = bb;
+            sB[hl] = bb;
         }
-        if (lane == 0) {
+        if (hl == 0) {
             sSC[0] = (reach && !last ? cs * 2.0 * D->R : 0.0) + lm;  // Huu diagonal
             sSC[1] = lm;                                              // LM on the velocity diagonal
             sSC[2] = nn_on ? (last ? D->nn_soft_e : D->nn_soft_run) : -1.0;
             sSC[3] = 0.0;
         }
-        if (lane < NRT) {
-            const int r = lane;
+        for (int r = hl; r < NRT; r += 32) {
             double lo = -QP_ABSENT, hi = QP_ABSENT;
             if (r < rT0) {
                 const size_t bo = (size_t)b * bnd_stride + (size_t)k * NX + r;  // bnd_stride = 0: bounds shared by all instances
@@ -582,17 +614,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             sHI[r] = hi;
         }
         // z = 0 except the fixed dx_0; z_aff, z+ start defined
-        if (lane < NZ) {
-            const double z0 = (k == 0 && lane >= NU) ? sX0[lane - NU] : 0.0;
-            sZ[lane] = z0; sZA[lane] = z0; sZN[lane] = z0;
+        if (hl < NZ) {
+            const double z0 = (k == 0 && hl >= NU) ? sX0[hl - NU] : 0.0;
+            sZ[hl] = z0; sZA[hl] = z0; sZN[hl] = z0;
         }
-        for (int el = lane; el < Ly.bH - Ly.bFac; el += 64) rec[Ly.bFac + el] = 0.0;
+        for (int el = hl; el < Ly.bH - Ly.bFac; el += 32) rec[Ly.bFac + el] = 0.0;
         lds_fence();
         // initial slacks / multipliers
         double r0_loc = 0.0;
         int cnt = 0;
-        if (lane < NRT) {
-            const int r = lane;
+        for (int r = hl; r < NRT; r += 32) {
             const double cz = row_dot(r, sZ);
             const bool soft = (r == rNN) && sSC[2] >= 0.0;
             double tl = 1.0, ll = 0.0, tu = 1.0, lu = 0.0;
@@ -618,30 +649,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             sTL[r] = tl; sLL[r] = ll; sTU[r] = tu; sLU[r] = lu;
             sE[r] = -(ll - lu);
         }
-        if (lane == 0 && !(sSC[2] >= 0.0)) sSL[0] = 0.0;
-        if (lane == 1) sSL[1] = 0.0;
+        if (hl == 0 && !(sSC[2] >= 0.0)) sSL[0] = 0.0;
+        if (hl == 1) sSL[1] = 0.0;
         lds_fence();
         // stationarity residual at the initial point (pi = 0): g - C^T (ll - lu); dx_0 does not enter (no cost cross term)
-        if (lane < NZ && !(k == 0 && lane >= NU) && !(last && lane < NU))
-            r0_loc = fmax(r0_loc, fabs(sGZ[lane] + ct_dot(lane, sE)));
-        if (!last && lane < NX) {
+        if (hl < NZ && !(k == 0 && hl >= NU) && !(last && hl < NU))
+            r0_loc = fmax(r0_loc, fabs(sGZ[hl] + ct_dot(hl, sE)));
+        if (!last && hl < NX) {
             double ax = 0.0;  // dynamics defect of the initial point: next dx is 0
-            if (k == 0) ax = lane < NQ ? sX0[lane] + dt * sX0[NQ + lane] : sX0[lane];
-            r0_loc = fmax(r0_loc, fabs(ax + sB[lane]));
+            if (k == 0) ax = hl < NQ ? sX0[hl] + dt * sX0[NQ + hl] : sX0[hl];
+            r0_loc = fmax(r0_loc, fabs(ax + sB[hl]));
         }
-        R0 = fmax(R0, wave_max(r0_loc));
-        m_comp += (int)wave_sum((double)cnt);
+        R0 = fmax(R0, half_max(r0_loc));
+        m_comp += (int)half_sum((double)cnt);
         {
-            const double bmax = wave_max(lane < NX ? fabs(sB[lane]) : 0.0);
-            if (lane == 0) sSC[3] = bmax > 0.0 ? 1.0 : 0.0;
+            const double bmax = half_max(hl < NX ? fabs(sB[hl]) : 0.0);
+            if (hl == 0) sSC[3] = bmax > 0.0 ? 1.0 : 0.0;
             lds_fence();
         }
         write_back(ws + (size_t)k * Ly.stride, rec, Ly.stride);
         lds_fence();
     }
+    QPT(13);
     if (m_comp == 0) m_comp = 1;
     const double inv_m = 1.0 / (double)m_comp;
-    double mu = wave_sum(mu_acc) * inv_m;
+    double mu = half_sum(mu_acc) * inv_m;
 
     // =====================================================================================================================
     // main loop
@@ -667,10 +699,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             const bool last = (k == N);
             commit(rec, Ly.stride);
             lds_fence();
+            QPT(0);
             if (k > 0) prefetch(ws + (size_t)(k - 1) * Ly.stride, Ly.stride);
             // -- rows: (apply step) + barrier weights + predictor coefficients; every lane touches only its own row
-            if (lane < NRT) {
-                const int r = lane;
+            for (int r = hl; r < NRT; r += 32) {
                 if (pending) {
                     const Dir d = row_dir(r, row_dot(r, sZN), sigmu, corr_w, row_dot(r, sZA));
                     if (sLO[r] > -QP_ABSENT) {
@@ -688,19 +720,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 sD[r] = Dr;
                 mu_new += row_comp(r);
             }
-            if (pending && lane < NZ) sZ[lane] += alpha * (sZN[lane] - sZ[lane]);
+            if (pending && hl < NZ) sZ[hl] += alpha * (sZN[hl] - sZ[hl]);
             const bool bflag = !last && sSC[3] != 0.0;
-            if (!last && lane < NX) {
+            if (!last && hl < NX) {
                 double a = 0.0;
                 if (bflag) {
 #pragma unroll
-                    for (int jx = 0; jx < NX; jx++) a = fma(Pc[lane * NX + jx], sB[jx], a);
+                    for (int jx = 0; jx < NX; jx++) a = fma(Pc[hl * NX + jx], sB[jx], a);
                 }
-                sPB[lane] = a;
+                sPB[hl] = a;
             }
             lds_fence();
+            QPT(1);
             // -- fused assembly: H + C^T D C, with B^T P B / B^T P A folded into the u-rows, gradient, rho
-            for (int el = lane; el < NTRI_Z; el += 64) {
+            for (int el = hl; el < NTRI_Z; el += 32) {
                 const int i = triZi[el], j = triZj[el];
                 double a = 0.0;
 #pragma unroll
@@ -737,33 +770,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     sG[i * WS + jx] = a;
                 }
             }
-            if (lane < NZ) {
-                const double gh = sGZ[lane] + ct_dot(lane, sE);
+            if (hl < NZ) {
+                const double gh = sGZ[hl] + ct_dot(hl, sE);
                 if (last) {
-                    if (lane >= NU) pvn[lane - NU] = gh;
-                } else if (lane < NU) {
+                    if (hl >= NU) pvn[hl - NU] = gh;
+                } else if (hl < NU) {
                     // rho = gh_u + B^T (p_{k+1} + P b)
-                    sG[lane * WS + NX] = gh + cB * (pvc[lane] + sPB[lane]) + dt * (pvc[NQ + lane] + sPB[NQ + lane]);
+                    sG[hl * WS + NX] = gh + cB * (pvc[hl] + sPB[hl]) + dt * (pvc[NQ + hl] + sPB[NQ + hl]);
                 } else {
-                    sGH[lane] = gh;
+                    sGH[hl] = gh;
                 }
             }
             lds_fence();
+            QPT(2);
             if (!last) {
                 if (!chol_from_lds(sLam)) broke = true;
                 // [W | w] = L^-1 [G | rho], one column per lane
-                if (lane <= NX) {
+                if (hl <= NX) {
                     double col[NQ];
 #pragma unroll
                     for (int i = 0; i < NQ; i++) {
-                        double v = sG[i * WS + lane];
+                        double v = sG[i * WS + hl];
 #pragma unroll
                         for (int t = 0; t < i; t++) v = fma(-Lr[i][t], col[t], v);
                         col[i] = v * Linv[i];
-                        sW[i * WS + lane] = col[i];
+                        sW[i * WS + hl] = col[i];
                     }
                 }
-                if (lane == 0) {
+                if (hl == 0) {
 #pragma unroll
                     for (int i = 0; i < NQ; i++) {
 #pragma unroll
@@ -771,9 +805,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     }
                 }
                 lds_fence();
+                QPT(3);
                 if (k > 0) {
                     // P_k = Hxx + A^T P A - W^T W (upper triangle, mirrored into the other buffer) and p_k
-                    for (int el = lane; el < NTRI_X; el += 64) {
+                    for (int el = hl; el < NTRI_X; el += 32) {
                         const int i = triXi[el], j = triXj[el];
                         double a = sHXX[i * NX + j];
                         // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]
@@ -788,8 +823,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         Pn[i * NX + j] = a;
                         Pn[j * NX + i] = a;
                     }
-                    if (lane < NX) {
-                        const int i = lane;
+                    if (hl < NX) {
+                        const int i = hl;
                         // p_k = gh_x + A^T (p_{k+1} + P b) - W^T w
                         double v = sGH[NU + i] + (i < NQ ? pvc[i] + sPB[i]
                                                          : dt * (pvc[i - NQ] + sPB[i - NQ]) + pvc[i] + sPB[i]);
@@ -799,6 +834,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     }
                 }
             }
+            QPT(4);
             // write back what changed: state + z (if a step was applied) and the factors
             double* w = ws + (size_t)k * Ly.stride;
             if (pending) write_back(w + Ly.bState, rec + Ly.bState, Ly.bFac - Ly.bState);
@@ -808,12 +844,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 double* t1 = Pc; Pc = Pn; Pn = t1;
                 double* t2 = pvc; pvc = pvn; pvn = t2;
             }
+            QPT(5);
             asm volatile("; QPMARK B1_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (wave_max(broke ? 1.0 : 0.0) > 0.0) { st_code = 4; pending = false; break; }
+        if (half_max(broke ? 1.0 : 0.0) > 0.0) { st_code = 4; pending = false; break; }
         if (pending) {
-            mu = wave_sum(mu_new) * inv_m;
+            mu = half_sum(mu_new) * inv_m;
             pending = false;
             if (!(mu == mu)) { st_code = 4; break; }
         }
@@ -828,20 +865,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             asm volatile("; QPMARK F1_BEGIN");
             commit(rec, Ly.nPrefix);
             lds_fence();
+            QPT(6);
             if (k < N) { prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix); load_L_regs(); }
             roll_out(k < N, xr, zr);
-            if (lane < NRT) {
-                const Dir d = row_dir(lane, row_dot_reg(lane, zr), 0.0, 0.0, 0.0);
-                amin = fmin(amin, row_ratio(lane, d, &S1, &S2));
+            for (int r = hl; r < NRT; r += 32) {
+                const Dir d = row_dir(r, row_dot_reg(r, zr), 0.0, 0.0, 0.0);
+                amin = fmin(amin, row_ratio(r, d, &S1, &S2));
             }
-            if (lane < NZ) ws[(size_t)k * Ly.stride + Ly.oZA + lane] = sel(zr, TagNZ{}, lane);
+            if (hl < NZ) ws[(size_t)k * Ly.stride + Ly.oZA + hl] = sel(zr, TagNZ{}, hl);
             lds_fence();
+            QPT(7);
             asm volatile("; QPMARK F1_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        const double a_aff = fmin(1.0, wave_min(amin));
-        S1 = wave_sum(S1);
-        S2 = wave_sum(S2);
+        const double a_aff = fmin(1.0, half_min(amin));
+        S1 = half_sum(S1);
+        S2 = half_sum(S2);
         const double mu_aff = (mu * (double)m_comp + a_aff * S1 + a_aff * a_aff * S2) * inv_m;
         double sigma = mu_aff / mu;
         sigma = fmin(sigma * sigma * sigma, 0.3);  // centring cap (see oracle): halves the iteration tail
@@ -856,20 +895,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             const bool last = (k == N);
             commit(rec, Ly.nPrefix);
             lds_fence();
+            QPT(8);
             if (k > 0) prefetch(ws + (size_t)(k - 1) * Ly.stride, Ly.nPrefix);
-            if (lane < NRT) {
+            for (int r = hl; r < NRT; r += 32) {
                 double Dr;
-                sE[lane] = row_coeff(lane, sigmu, corr_w, row_dot(lane, sZA), &Dr);
+                sE[r] = row_coeff(r, sigmu, corr_w, row_dot(r, sZA), &Dr);
             }
             lds_fence();
-            if (lane < NZ) {
-                const double gh = sGZ[lane] + ct_dot(lane, sE);
+            if (hl < NZ) {
+                const double gh = sGZ[hl] + ct_dot(hl, sE);
                 if (last) {
-                    if (lane >= NU) pvn[lane - NU] = gh;
-                } else if (lane < NU) {
-                    sRho[lane] = gh + cB * (pvc[lane] + sPB[lane]) + dt * (pvc[NQ + lane] + sPB[NQ + lane]);
+                    if (hl >= NU) pvn[hl - NU] = gh;
+                } else if (hl < NU) {
+                    sRho[hl] = gh + cB * (pvc[hl] + sPB[hl]) + dt * (pvc[NQ + hl] + sPB[NQ + hl]);
                 } else {
-                    sGH[lane] = gh;
+                    sGH[hl] = gh;
                 }
             }
             lds_fence();
@@ -883,17 +923,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int t = 0; t < i; t++) v = fma(-Lr[i][t], wv[t], v);
                     wv[i] = v * Linv[i];
                 }
-                if (k > 0 && lane < NX) {
-                    const int i = lane;
+                if (k > 0 && hl < NX) {
+                    const int i = hl;
                     double v = sGH[NU + i] + (i < NQ ? pvc[i] + sPB[i] : dt * (pvc[i - NQ] + sPB[i - NQ]) + pvc[i] + sPB[i]);
 #pragma unroll
                     for (int t = 0; t < NQ; t++) v = fma(-sW[t * WS + i], wv[t], v);
                     pvn[i] = v;
                 }
-                if (lane < NQ) ws[(size_t)k * Ly.stride + Ly.oW + lane * WS + NX] = sel(wv, TagNQ{}, lane);
+                if (hl < NQ) ws[(size_t)k * Ly.stride + Ly.oW + hl * WS + NX] = sel(wv, TagNQ{}, hl);
             }
             lds_fence();
             if (last || k > 0) { double* t2 = pvc; pvc = pvn; pvn = t2; }
+            QPT(9);
             asm volatile("; QPMARK B2_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -908,20 +949,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             asm volatile("; QPMARK F2_BEGIN");
             commit(rec, Ly.nPrefix);
             lds_fence();
+            QPT(10);
             if (k < N) { prefetch(ws + (size_t)(k + 1) * Ly.stride, Ly.nPrefix); load_L_regs(); }
             roll_out(k < N, xr, zr);
-            if (lane < NRT) {
-                const Dir d = row_dir(lane, row_dot_reg(lane, zr), sigmu, corr_w, row_dot(lane, sZA));
-                amin = fmin(amin, row_ratio(lane, d, &S1c, &S2c));
+            for (int r = hl; r < NRT; r += 32) {
+                const Dir d = row_dir(r, row_dot_reg(r, zr), sigmu, corr_w, row_dot(r, sZA));
+                amin = fmin(amin, row_ratio(r, d, &S1c, &S2c));
             }
-            if (lane < NZ) ws[(size_t)k * Ly.stride + Ly.oZN + lane] = sel(zr, TagNZ{}, lane);
+            if (hl < NZ) ws[(size_t)k * Ly.stride + Ly.oZN + hl] = sel(zr, TagNZ{}, hl);
             lds_fence();
+            QPT(11);
             asm volatile("; QPMARK F2_END");
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // fraction to the boundary (see oracle): 0.995, approaching 1 with the complementarity (cap 0.9999) when the step is
         // within 1% of the full Newton step; an earlier-blocked step keeps the classical margin to stay centred
-        const double a_max = wave_min(amin);
+        const double a_max = half_min(amin);
         const double tau_k = a_max >= 0.99 ? fmin(0.9999, fmax(QP_FTB, 1.0 - mu)) : QP_FTB;
         alpha = fmin(1.0, tau_k * a_max);
         if (!(alpha == alpha)) { st_code = 4; break; }
@@ -929,7 +972,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         pending = true;
         rho_lin *= (1.0 - alpha);
         // sum(lambda t) is a quadratic in the step length: the new complementarity is known before the step is applied
-        mu = (mu * (double)m_comp + alpha * wave_sum(S1c) + alpha * alpha * wave_sum(S2c)) * inv_m;
+        mu = (mu * (double)m_comp + alpha * half_sum(S1c) + alpha * alpha * half_sum(S2c)) * inv_m;
         if (!(mu == mu)) { st_code = 4; pending = false; break; }
     }
     if (it == max_iter && st_code == 2 && mu <= tol && rho_lin * R0 <= tol) st_code = 0;
@@ -940,21 +983,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     for (int k = 0; k <= N; k++) {
         const double* zk = ws + (size_t)k * Ly.stride + Ly.oZ;
         const double* zn = ws + (size_t)k * Ly.stride + Ly.oZN;
-        if (lane < NX) {
-            const double z = zk[NU + lane];
-            const double v = xb[(size_t)k * NX + lane] + z + a_fin * (zn[NU + lane] - z);
-            x_out[((size_t)b * (N + 1) + k) * NX + lane] = v;
+        if (hl < NX) {
+            const double z = zk[NU + hl];
+            const double v = xb[(size_t)k * NX + hl] + z + a_fin * (zn[NU + hl] - z);
+            x_out[((size_t)b * (N + 1) + k) * NX + hl] = v;
             bad |= !(v == v);
         }
-        if (k < N && lane < NU) {
-            const double z = zk[lane];
-            const double v = ub[(size_t)k * NU + lane] + z + a_fin * (zn[lane] - z);
-            u_out[((size_t)b * N + k) * NU + lane] = v;
+        if (k < N && hl < NU) {
+            const double z = zk[hl];
+            const double v = ub[(size_t)k * NU + hl] + z + a_fin * (zn[hl] - z);
+            u_out[((size_t)b * N + k) * NU + hl] = v;
             bad |= !(v == v);
         }
     }
-    const bool any_bad = wave_max(bad ? 1.0 : 0.0) > 0.0;
-    if (lane == 0) {
+    const bool any_bad = half_max(bad ? 1.0 : 0.0) > 0.0;
+#ifdef QP_PROFILE
+    QPT(12);
+    if (hl == 0) {
+        for (int i = 0; i < 14; i++) atomicAdd(&g_qp_prof[i], tacc[i]);
+        atomicAdd(&g_qp_prof[14], 1ull);
+        atomicAdd(&g_qp_prof[15], (unsigned long long)it);
+    }
+#endif
+    if (hl == 0) {
         // acados' RTI tolerates a QP that stopped at its iteration cap (see oracle); breakdown / min-step are QP failures
         int stc = (st_code == 0 || st_code == 2) ? SMPC_STATUS_SUCCESS : SMPC_STATUS_QP_FAILURE;
         if (any_bad && stc == SMPC_STATUS_SUCCESS) stc = SMPC_STATUS_NAN;
