@@ -250,12 +250,18 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         hipLaunchKernelGGL(k_order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->d_last_it, h->d_order);
         order = h->d_order;
     }
-    if (h->desc.n_rows == 6)
-        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
-                           bhi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it, bstride);
-    else
-        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,
-                           bhi, h->d_ev, h->d_ws, xo, uo, st, it, order, h->d_last_it, bstride);
+    const int pairs = (int)(((long)B * (h->N + 1) + 1) / 2);
+    if (h->desc.n_rows == 6) {
+        hipLaunchKernelGGL((k_qp_setup<NQ, 6>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,
+                           h->d_ev, h->d_ws, bstride);
+        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
+                           xo, uo, st, it, order, h->d_last_it);
+    } else {
+        hipLaunchKernelGGL((k_qp_setup<NQ, -1>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,
+                           h->d_ev, h->d_ws, bstride);
+        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
+                           xo, uo, st, it, order, h->d_last_it);
+    }
     h->order_B = B;
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream));
@@ -294,16 +300,10 @@ int smpc_create(const smpc_problem_desc* desc, int device, smpc_handle** out) {
         if (row.kind < 0 || row.kind > SMPC_ROW_COORD || row.pa < 0 || row.pa >= desc->n_points)
             return fail(nullptr, SMPC_EINVAL, "row %d malformed", r);
     }
-    {
-        size_t stride = 0, cap = 0;
-        switch (desc->nq) {
-        case 5: stride = QpLayout<5>(desc->n_rows).stride; cap = QpPf<5>::value * 64; break;
-        case 6: stride = QpLayout<6>(desc->n_rows).stride; cap = QpPf<6>::value * 64; break;
-        default: stride = QpLayout<7>(desc->n_rows).stride; cap = QpPf<7>::value * 64; break;
-        }
-        if (stride > cap || sizeof(smpc_node_eval) / sizeof(double) > cap)
-            return fail(nullptr, SMPC_EINVAL, "stage record of %zu doubles exceeds the kernel's staging buffer (%zu)", stride, cap);
-    }
+    // k_qp_ipm gives every two-sided constraint row (x box, torque, collision, safe-set) its own lane of a half-wavefront
+    if (3 * desc->nq + desc->n_rows + 1 > 32)
+        return fail(nullptr, SMPC_EINVAL, "3*nq + n_rows + 1 = %d constraint rows per stage exceed the 32 lanes of a half-wavefront",
+                    3 * desc->nq + desc->n_rows + 1);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, SMPC_EHIP, "no HIP device visible: the engine has no CPU fallback");

@@ -37,11 +37,11 @@ out = s.solve(xd, xgd, ugd, pd)
 qp_ms = s.timing()['time_qp'] * 1e3
 L.smpc_debug_qp_profile(buf)
 v = np.array(list(buf), dtype=np.float64)
-names = ['B1 record wait', 'B1 rows', 'B1 assembly', 'B1 chol+W', 'B1 P update', 'B1 write-back', 'F1 record wait', 'F1 compute',
-         'B2 record wait', 'B2 compute', 'F2 record wait', 'F2 compute', 'epilogue', 'phase 0']
+names = ['B1 commit+rows', 'B1 P b, D-scaling', 'B1 assembly+grad', 'B1 chol+columns', 'B1 P update', 'B1 end fence',
+         'F1 control', 'F1 rows', 'B2 rows', 'B2 recursion', 'F2 control', 'F2 rows', 'epilogue', 'prologue']
 waves, its = v[14], v[15]
 tot = v[:14].sum()
-print('B %d  QP %.3f ms  waves %d  mean iterations (per reporting half) %.2f' % (B, qp_ms, waves, its / max(waves, 1)))
-print('mean clocks per wave %.0f  (kernel time = %.0f clocks at 2.4 GHz)' % (tot / waves, qp_ms * 2.4e6))
+print('B %d  QP (setup + ipm) %.3f ms  half-waves %d  mean iterations %.2f' % (B, qp_ms, waves, its / max(waves, 1)))
+print('mean clocks per half-wave %.0f  (kernel time = %.0f clocks at 2.4 GHz)' % (tot / waves, qp_ms * 2.4e6))
 for n, c in zip(names, v[:14]):
     print('  %-16s %5.1f %%   %9.0f clocks/wave' % (n, 100 * c / tot, c / waves))
