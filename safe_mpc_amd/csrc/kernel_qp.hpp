@@ -20,8 +20,14 @@
 //     registers, re-loaded for the next stage right after its last use in this one (a full stage of latency cover);
 //   * LDS holds only what lanes exchange: the vectors of the recursions (x, u, costate, row coefficients) and, in B1, the
 //     matrices of the factorisation (transposed Jacobian image, P ping-pong, Lambda, G, W);
-//   * the factorisation stores the gain in closed form (K = Lambda^-1 G, L^-1), so the three light sweeps are
-//     lane-parallel matrix-vector products separated by wave-scope LDS fences (no s_barrier, no vmcnt drain).
+//   * the factorisation stores the gain in closed form (K = Lambda^-1 G, k; W = L^-1 G and L^-1 for the costate -- the
+//     symmetric two-step form keeps the corrector solve as accurate as substitution), so the three light sweeps are
+//     lane-parallel matrix-vector products separated by wave-scope LDS fences (no s_barrier, no vmcnt drain);
+//   * every vector-memory instruction of a stage is unconditional and straight-line (row arrays padded to 32 lanes with
+//     "absent" rows, lane and stage indices clamped instead of branched on, the horizon's end stage peeled off): gfx9
+//     counts loads and stores in ONE in-order vmcnt, and the compiler can only wait for "all but the n youngest" when
+//     n is the same on every path -- a single conditional load otherwise turns each wait into vmcnt(0) and serialises
+//     the stage on the loads it has just issued for the next one.
 // The double integrator's A, B are never stored (env_model.py:63-67): every product with them is expanded in closed form.
 //
 // The algorithm is the one restated in oracle/smpc_oracle.cpp::qp_ipm (same initial point, Mehrotra rule, step rule and
@@ -45,20 +51,21 @@ constexpr int qp_even_c(int n) { return (n + 1) & ~1; }
 template <int NQ> struct QpLayout {
     static constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ;
     static constexpr int NZP = qp_even_c(NZ), NQP = qp_even_c(NQ), WS2 = qp_even_c(NX + 1);
-    int MR, MRP, NRC, NRT, NRTP;
+    static constexpr int NL = 32;       // lanes of a half-wave = padded length of every per-row / per-variable array
+    static constexpr int LC0 = WS2;     // first column of L^-1 inside the rows of W
+    int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
     // static blocks
     int oC, oLO, oHI, oIMG;
     // dynamic blocks
-    int oTL, oTU, oLL, oLU, oCZA, oDTL, oDTU, oDLL, oDLU, oSL, oZ, oZN, oK, oW, oLI, oPB, oPART;
+    int oTL, oTU, oLL, oLU, oCZA, oDTL, oDTU, oDLL, oDLU, oSL, oZ, oZN, oK, oW, oPB, oDUM, oPART;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
         MR = n_rows;
         MRP = qp_even_c(MR);
         NRC = NQ + MR + 1;
         NRT = NX + NRC;
-        NRTP = qp_even_c(NRT);
         int i = 0;
         iTT = i; i += NZ * NQP;            // torque rows transposed: Tt[c][r]
         iGT = i; i += NQ * MRP;            // collision rows transposed (q columns): Gt[ix][r]
@@ -67,29 +74,29 @@ template <int NQ> struct QpLayout {
         iGZ = i; i += NZP;                 // cost gradient
         iB = i; i += NX;                   // dynamics defect
         iSC = i; i += 4;                   // [Huu diagonal, LM on the v diagonal, soft weight, b != 0]
-        nIMG = i;
+        nIMG = (i + 63) & ~63;             // whole 16-byte loads for all 32 lanes
         int o = 0;
         oC = o; o += NRC * NZP;            // general rows, row-major (F: rows, B2: columns)
-        oLO = o; o += NRTP;
-        oHI = o; o += NRTP;
-        oIMG = o; o += nIMG;
-        oTL = o; o += NRTP;
-        oTU = o; o += NRTP;
-        oLL = o; o += NRTP;
-        oLU = o; o += NRTP;
-        oCZA = o; o += NRTP;               // c . z_aff of every row (F1 -> B2, F2)
-        oDTL = o; o += NRTP;               // step directions of every row (F2 -> B1)
-        oDTU = o; o += NRTP;
-        oDLL = o; o += NRTP;
-        oDLU = o; o += NRTP;
-        oSL = o; o += 4;                   // [soft slack, its direction, soft weight, b != 0]
-        oZ = o; o += NZP;
-        oZN = o; o += NZP;
-        oK = o; o += NQ * WS2;             // feedback gain rows [K_i | k_i]
-        oW = o; o += NQ * WS2;             // W = L^-1 G
-        oLI = o; o += NQ * NQP;            // L^-1
-        oPB = o; o += NX;                  // P b
+        oLO = o; o += NL;                  // rows >= NRT are "absent" on both sides
+        oHI = o; o += NL;
+        oTL = o; o += NL;
+        oTU = o; o += NL;                  // (the soft row has no upper side: its slack lives here)
+        oLL = o; o += NL;
+        oLU = o; o += NL;
+        oCZA = o; o += NL;                 // c . z_aff of every row (F1 -> B2, F2)
+        oDTL = o; o += NL;                 // step directions of every row (F2 -> B1)
+        oDTU = o; o += NL;
+        oDLL = o; o += NL;
+        oDLU = o; o += NL;
+        oSL = o; o += 2;                   // [soft weight, b != 0]
+        oZ = o; o += NL;
+        oZN = o; o += NL;
+        oK = o; o += NQ * NL;              // gain rows [K_i | k_i | ...]            = L^-T L^-1 [G | rho | I]
+        oW = o; o += NQ * NL;              // half-way rows [W_i | w_i | . | L^-1_i | .] = L^-1 [G | rho | I]
+        oPB = o; o += NL;                  // P b
+        oDUM = o; o += NL;                 // landing zone of the lanes that have nothing to store
         oPART = o; o += 4;                 // setup partials [R0, sum lambda t, count]
+        oIMG = o; o += nIMG;
         stride = qp_even_c(o);
     }
     __host__ __device__ size_t per_instance(int N) const { return (size_t)stride * (N + 1); }
@@ -137,143 +144,96 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 
 // ---- per-row IPM algebra: one lane owns one two-sided row (lo <= c.z <= hi), everything in its registers -----------------
+// Absent sides carry t = 1, lambda = 0 and are masked out by selects (no divergent branches: the lanes of a half-wave own
+// rows of every kind).  The soft row (safe-set constraint relaxed by an L1-penalised slack, eliminated in closed form)
+// has no upper side; its slack and the slack's direction use the upper side's slots (tu, dtu).
 struct QpRow { double lo, hi, tl, tu, ll, lu; };
-struct QpDir { double dtl, dll, dtu, dlu, dsl; };
+struct QpDir { double dtl, dll, dtu, dlu; };
 
-// directions for the trial value czn = c.z+ ; cw != 0: subtract the Mehrotra second-order term built from cza = c.z_aff.
-// soft: the row's lower side is relaxed by an L1-penalised slack sl (weight wsoft), eliminated in closed form
-__device__ __forceinline__ QpDir qp_row_dir(const QpRow& s, bool soft, double wsoft, double sl, double czn, double sigmu,
-                                            double cw, double cza) {
-    const bool corr = cw != 0.0;
-    QpDir o{0.0, 0.0, 0.0, 0.0, 0.0};
-    if (s.lo > -QP_ABSENT) {
-        const double tl = s.tl, ll = s.ll;
-        if (soft) {
-            const double nu = wsoft - ll;
-            const double ill = fast_rcp(ll), inu = fast_rcp(nu);
-            const double deff = fast_rcp(tl * ill + sl * inu);
-            double ct = 0.0, cs2 = 0.0;
-            if (corr) {
-                const double dla = -deff * (cza - s.lo);
-                const double dta = -tl * dla * ill - tl;
-                const double dsa = sl * dla * inu - sl;
-                ct = cw * dta * dla;
-                cs2 = -cw * dsa * dla;
-            }
-            const double dl = -deff * (czn - s.lo + (sigmu - cs2) * inu - (sigmu - ct) * ill);
-            o.dll = dl;
-            o.dtl = (sigmu - ct - tl * dl) * ill - tl;
-            o.dsl = (sigmu - cs2 + sl * dl) * inu - sl;
-        } else {
-            const double itl = fast_rcp(tl);
-            double ct = 0.0;
-            if (corr) {
-                const double dta = cza - s.lo - tl;
-                const double dla = -ll * dta * itl - ll;
-                ct = cw * dta * dla;
-            }
-            const double dt_ = czn - s.lo - tl;
-            o.dtl = dt_;
-            o.dll = (sigmu - ct - ll * dt_) * itl - ll;
-        }
-    }
-    if (s.hi < QP_ABSENT) {
-        const double tu = s.tu, lu = s.lu;
-        const double itu = fast_rcp(tu);
-        double ct = 0.0;
-        if (corr) {
-            const double dta = s.hi - cza - tu;
-            const double dla = -lu * dta * itu - lu;
-            ct = cw * dta * dla;
-        }
-        const double dt_ = s.hi - czn - tu;
-        o.dtu = dt_;
-        o.dlu = (sigmu - ct - lu * dt_) * itu - lu;
+// one side: gap = distance of the trial point to the bound, gap_a the same for z_aff; returns the largest -d/v in *rr
+__device__ __forceinline__ void qp_side_dir(bool has, double gap, double gap_a, double t, double l, double sigmu, double cw,
+                                            double* dt_o, double* dl_o, double* rr, double* S1, double* S2) {
+    const double ls = has ? l : 1.0;
+    const double r = fast_rcp(t * ls);      // one reciprocal serves 1/t and 1/lambda
+    const double it = ls * r, il = t * r;
+    const double dta = gap_a - t;
+    const double dla = -l * dta * it - l;
+    const double ct = cw * dta * dla;       // Mehrotra second-order term (cw = 0: predictor)
+    const double dtt = gap - t;
+    const double dll = (sigmu - ct - l * dtt) * it - l;
+    const double dt_ = has ? dtt : 0.0, dl_ = has ? dll : 0.0;
+    *dt_o = dt_;
+    *dl_o = dl_;
+    *rr = fmax(*rr, fmax(-dt_ * it, -dl_ * il));
+    *S1 += l * dt_ + t * dl_;
+    *S2 += dl_ * dt_;
+}
+// directions of one row for the trial value czn = c.z+, ratio-test term and the terms of sum(lambda t)(alpha)
+__device__ __forceinline__ QpDir qp_row_dir(const QpRow& s, bool soft, double wsoft, double czn, double sigmu, double cw,
+                                            double cza, double* rr, double* S1, double* S2) {
+    QpDir o;
+    const bool hasl = s.lo > -QP_ABSENT, hasu = s.hi < QP_ABSENT;
+    const double lo = hasl ? s.lo : 0.0, hi = hasu ? s.hi : 0.0;
+    qp_side_dir(hasl && !soft, czn - lo, cza - lo, s.tl, s.ll, sigmu, cw, &o.dtl, &o.dll, rr, S1, S2);
+    qp_side_dir(hasu, hi - czn, hi - cza, s.tu, s.lu, sigmu, cw, &o.dtu, &o.dlu, rr, S1, S2);
+    if (soft) {
+        const double tl = s.tl, ll = s.ll, sl = s.tu;
+        const double nu = wsoft - ll;
+        const double ill = fast_rcp(ll), inu = fast_rcp(nu);
+        const double deff = fast_rcp(tl * ill + sl * inu);
+        const double dla = -deff * (cza - lo);
+        const double dta = -tl * dla * ill - tl;
+        const double dsa = sl * dla * inu - sl;
+        const double ct = cw * dta * dla;
+        const double cs2 = -cw * dsa * dla;
+        const double dl = -deff * (czn - lo + (sigmu - cs2) * inu - (sigmu - ct) * ill);
+        const double dtl = (sigmu - ct - tl * dl) * ill - tl;
+        const double dsl = (sigmu - cs2 + sl * dl) * inu - sl;
+        o.dll = dl;
+        o.dtl = dtl;
+        o.dtu = dsl;
+        *rr = fmax(*rr, fmax(fmax(-dtl / tl, -dl * ill), fmax(-dsl / sl, dl * inu)));
+        *S1 += ll * dtl + tl * dl + nu * dsl - sl * dl;
+        *S2 += dl * dtl - dl * dsl;
     }
     return o;
 }
 // gradient coefficient e_r (returned) and barrier weight D_r
-__device__ __forceinline__ double qp_row_coeff(const QpRow& s, bool soft, double wsoft, double sl, double sigmu, double cw,
-                                               double cza, double* Dr) {
-    const bool corr = cw != 0.0;
-    double e = 0.0, dsum = 0.0;
-    if (s.lo > -QP_ABSENT) {
-        const double tl = s.tl, ll = s.ll;
-        if (soft) {
-            const double nu = wsoft - ll;
-            const double ill = fast_rcp(ll), inu = fast_rcp(nu);
-            const double deff = fast_rcp(tl * ill + sl * inu);
-            double ct = 0.0, cs2 = 0.0;
-            if (corr) {
-                const double dla = -deff * (cza - s.lo);
-                const double dta = -tl * dla * ill - tl;
-                const double dsa = sl * dla * inu - sl;
-                ct = cw * dta * dla;
-                cs2 = -cw * dsa * dla;
-            }
-            e += -ll + deff * (-s.lo + (sigmu - cs2) * inu - (sigmu - ct) * ill);
-            dsum += deff;
-        } else {
-            const double itl = fast_rcp(tl);
-            double ct = 0.0;
-            if (corr) {
-                const double dta = cza - s.lo - tl;
-                const double dla = -ll * dta * itl - ll;
-                ct = cw * dta * dla;
-            }
-            const double d = ll * itl;
-            e += -ll - d * s.lo - (sigmu - ct) * itl;
-            dsum += d;
-        }
+__device__ __forceinline__ double qp_row_coeff(const QpRow& s, bool soft, double wsoft, double sigmu, double cw, double cza,
+                                               double* Dr) {
+    const bool hasl = s.lo > -QP_ABSENT, hasu = s.hi < QP_ABSENT;
+    const double lo = hasl ? s.lo : 0.0, hi = hasu ? s.hi : 0.0;
+    double e, dsum;
+    {
+        const double itl = fast_rcp(s.tl), itu = fast_rcp(s.tu);
+        const double dtal = cza - lo - s.tl, dtau = hi - cza - s.tu;
+        const double ctl = cw * dtal * (-s.ll * dtal * itl - s.ll);
+        const double ctu = cw * dtau * (-s.lu * dtau * itu - s.lu);
+        const double dl = s.ll * itl, du = s.lu * itu;
+        const double el = -s.ll - dl * lo - (sigmu - ctl) * itl;
+        const double eu = s.lu - du * hi + (sigmu - ctu) * itu;
+        e = ((hasl && !soft) ? el : 0.0) + (hasu ? eu : 0.0);
+        dsum = ((hasl && !soft) ? dl : 0.0) + (hasu ? du : 0.0);
     }
-    if (s.hi < QP_ABSENT) {
-        const double tu = s.tu, lu = s.lu;
-        const double itu = fast_rcp(tu);
-        double ct = 0.0;
-        if (corr) {
-            const double dta = s.hi - cza - tu;
-            const double dla = -lu * dta * itu - lu;
-            ct = cw * dta * dla;
-        }
-        const double d = lu * itu;
-        e += lu - d * s.hi + (sigmu - ct) * itu;
-        dsum += d;
+    if (soft) {
+        const double tl = s.tl, ll = s.ll, sl = s.tu;
+        const double nu = wsoft - ll;
+        const double ill = fast_rcp(ll), inu = fast_rcp(nu);
+        const double deff = fast_rcp(tl * ill + sl * inu);
+        const double dla = -deff * (cza - lo);
+        const double dta = -tl * dla * ill - tl;
+        const double dsa = sl * dla * inu - sl;
+        const double ct = cw * dta * dla;
+        const double cs2 = -cw * dsa * dla;
+        e = -ll + deff * (-lo + (sigmu - cs2) * inu - (sigmu - ct) * ill);
+        dsum = deff;
     }
     *Dr = dsum;
     return e;
 }
-// largest step keeping this row's slacks / multipliers positive, and its terms of  sum(lambda t)(alpha)
-__device__ __forceinline__ double qp_row_ratio(const QpRow& s, bool soft, double wsoft, double sl, const QpDir& d, double* S1,
-                                               double* S2) {
-    double a = 1e300;
-    if (s.lo > -QP_ABSENT) {
-        if (d.dtl < 0.0) a = fmin(a, -s.tl / d.dtl);
-        if (d.dll < 0.0) a = fmin(a, -s.ll / d.dll);
-        *S1 += s.ll * d.dtl + s.tl * d.dll;
-        *S2 += d.dll * d.dtl;
-        if (soft) {
-            const double nu = wsoft - s.ll;
-            if (d.dsl < 0.0) a = fmin(a, -sl / d.dsl);
-            if (d.dll > 0.0) a = fmin(a, nu / d.dll);
-            *S1 += nu * d.dsl - sl * d.dll;
-            *S2 += -d.dll * d.dsl;
-        }
-    }
-    if (s.hi < QP_ABSENT) {
-        if (d.dtu < 0.0) a = fmin(a, -s.tu / d.dtu);
-        if (d.dlu < 0.0) a = fmin(a, -s.lu / d.dlu);
-        *S1 += s.lu * d.dtu + s.tu * d.dlu;
-        *S2 += d.dlu * d.dtu;
-    }
-    return a;
-}
-__device__ __forceinline__ double qp_row_comp(const QpRow& s, bool soft, double wsoft, double sl) {  // lambda t (+ nu s)
-    double acc = 0.0;
-    if (s.lo > -QP_ABSENT) {
-        acc += s.ll * s.tl;
-        if (soft) acc += (wsoft - s.ll) * sl;
-    }
-    if (s.hi < QP_ABSENT) acc += s.lu * s.tu;
+__device__ __forceinline__ double qp_row_comp(const QpRow& s, bool soft, double wsoft) {  // lambda t (+ nu s)
+    double acc = s.ll * s.tl + s.lu * s.tu;          // absent sides hold lambda = 0
+    if (soft) acc = s.ll * s.tl + (wsoft - s.ll) * s.tu;
     return acc;
 }
 
@@ -284,6 +244,7 @@ __device__ unsigned long long g_qp_prof[16];
 #else
 #define QPT(i) do { } while (0)
 #endif
+
 
 // =========================================================================================================================
 // k_qp_setup: stage records + initial interior point, one half-wave per (instance, stage)
@@ -296,8 +257,8 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
                                                  const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
                                                  long bnd_stride) {
     using LyT = QpLayout<NQ>;
-    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP;
-    constexpr int MAXRC = NQ + (MRT >= 0 ? MRT : SMPC_MAX_ROWS) + 1, MAXRTP = qp_even_c(NX + MAXRC);
+    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, NL = LyT::NL;
+    constexpr int MAXRC = NQ + (MRT >= 0 ? MRT : SMPC_MAX_ROWS) + 1;
     constexpr int EV_D = (int)(sizeof(smpc_node_eval) / sizeof(double)), EV_PAD = qp_even_c(EV_D);
     const int hl = threadIdx.x & 31, half = threadIdx.x >> 5;
     const long pi = 2L * blockIdx.x + half;
@@ -309,8 +270,8 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
     double* w = ws_all + (size_t)b * Ly.per_instance(N) + (size_t)k * Ly.stride;
     const double dt = D->dt, cB = 0.5 * dt * dt;
 
-    constexpr int O_C = EV_PAD, O_LO = O_C + MAXRC * NZP, O_HI = O_LO + MAXRTP, O_E = O_HI + MAXRTP, O_Z0 = O_E + MAXRTP,
-                  O_GZ = O_Z0 + NZP, O_B = O_GZ + NZP, HALF_D = O_B + NX;
+    constexpr int O_C = EV_PAD, O_LO = O_C + MAXRC * NZP, O_HI = O_LO + NL, O_E = O_HI + NL, O_Z0 = O_E + NL, O_GZ = O_Z0 + NL,
+                  O_B = O_GZ + NZP, HALF_D = O_B + NX;
     __shared__ __attribute__((aligned(16))) double smem[2 * HALF_D];
     double* const sEV = smem + half * HALF_D;
     double* const sC = sEV + O_C;
@@ -330,7 +291,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         for (int i = hl; i < EV_D / 2; i += 32) d2[i] = s2[i];
     }
     // z = 0 except the fixed dx_0
-    if (hl < NZP) sZ0[hl] = (k == 0 && hl >= NU && hl < NZ) ? x0[(size_t)b * NX + hl - NU] - xk[hl - NU] : 0.0;
+    sZ0[hl] = (k == 0 && hl >= NU && hl < NZ) ? x0[(size_t)b * NX + hl - NU] - xk[hl - NU] : 0.0;
     lds_fence();
     const smpc_node_eval& e = *reinterpret_cast<const smpc_node_eval*>(sEV);
     const double cs = last ? D->cost_scale_term : D->cost_scale_stage;
@@ -373,7 +334,8 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         }
         sB[hl] = bb;
     }
-    for (int r = hl; r < Ly.NRTP; r += 32) {
+    {
+        const int r = hl;   // rows >= NRT stay absent on both sides
         double lo = -QP_ABSENT, hi = QP_ABSENT;
         if (r < rT0) {
             const size_t bo = (size_t)b * bnd_stride + (size_t)k * NX + r;  // bnd_stride = 0: bounds shared by all instances
@@ -399,7 +361,8 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
 
     // ---- static blocks out ---------------------------------------------------------------------------------------------
     for (int el = hl; el < NRC * NZP; el += 32) w[Ly.oC + el] = sC[el];
-    for (int r = hl; r < Ly.NRTP; r += 32) { w[Ly.oLO + r] = sLO[r]; w[Ly.oHI + r] = sHI[r]; }
+    w[Ly.oLO + hl] = sLO[hl];
+    w[Ly.oHI + hl] = sHI[hl];
     double* img = w + Ly.oIMG;
     for (int el = hl; el < NZ * NQP; el += 32) {
         const int c = el / NQP, r = el - c * NQP;
@@ -420,11 +383,13 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         const double huu = (reach && !last ? cs * 2.0 * D->R : 0.0) + lm;
         img[Ly.iSC + hl] = hl == 0 ? huu : (hl == 1 ? lm : (hl == 2 ? wsoft : bflag));
     }
+    for (int el = Ly.iSC + 4 + hl; el < Ly.nIMG; el += 32) img[el] = 0.0;
 
     // ---- initial slacks / multipliers ----------------------------------------------------------------------------------
     double r0_loc = 0.0, mu_acc = 0.0;
     int cnt = 0;
-    for (int r = hl; r < Ly.NRTP; r += 32) {
+    {
+        const int r = hl;
         double tl = 1.0, ll = 0.0, tu = 1.0, lu = 0.0;
         if (r < NRT) {
             double cz;
@@ -443,7 +408,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
                 r0_loc = fmax(r0_loc, fabs(slack - tl));
                 cnt += soft ? 2 : 1;
                 mu_acc += ll * tl;
-                if (soft) mu_acc += (wsoft - ll) * s0;
+                if (soft) { mu_acc += (wsoft - ll) * s0; tu = s0; }   // the slack rides in the unused upper side
             }
             if (sHI[r] < QP_ABSENT) {
                 const double slack = sHI[r] - cz;
@@ -459,8 +424,10 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         w[Ly.oDTL + r] = 0.0; w[Ly.oDTU + r] = 0.0; w[Ly.oDLL + r] = 0.0; w[Ly.oDLU + r] = 0.0;
         sE[r] = -(ll - lu);
     }
-    if (hl < 4) w[Ly.oSL + hl] = hl == 0 ? (wsoft >= 0.0 ? QP_THR : 0.0) : (hl == 1 ? 0.0 : (hl == 2 ? wsoft : bflag));
-    if (hl < NZP) { w[Ly.oZ + hl] = sZ0[hl]; w[Ly.oZN + hl] = sZ0[hl]; }
+    if (hl < 2) w[Ly.oSL + hl] = hl == 0 ? wsoft : bflag;
+    w[Ly.oZ + hl] = sZ0[hl];
+    w[Ly.oZN + hl] = sZ0[hl];
+    w[Ly.oPB + hl] = 0.0;
     lds_fence();
     // stationarity residual at the initial point (pi = 0): g - C^T (ll - lu); dx_0 does not enter (no cost cross term)
     if (hl < NZ && !(k == 0 && hl >= NU) && !(last && hl < NU)) {
@@ -492,13 +459,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     int32_t* __restrict__ status, int32_t* __restrict__ qp_iter, const int32_t* __restrict__ order,
     int32_t* __restrict__ last_iter) {
     using LyT = QpLayout<NQ>;
-    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2;
+    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = LyT::NL,
+                  LC0 = LyT::LC0;
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS, MRP_MAX = qp_even_c(MR_MAX);
-    constexpr int NRC_MAX = NQ + MR_MAX + 1, NRT_MAX = NX + NRC_MAX;
-    static_assert(MRT < 0 || NRT_MAX <= 32, "one lane per constraint row");
+    constexpr int NRC_MAX = NQ + MR_MAX + 1;
+    static_assert(MRT < 0 || NX + NRC_MAX <= NL, "one lane per constraint row");
+    static_assert(LC0 + NQ <= NL, "one lane per column of [G | rho | I]");
     constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
-    constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
-    constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
+    constexpr int IMG_MAX = (NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4 + 63) & ~63;
+    constexpr int IMG_PF = IMG_MAX / 64;
 #ifdef QP_PROFILE
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -510,13 +479,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // call (instances are independent, so the order only changes the makespan, never a result)
     const int b = order ? order[slot] : slot;
     const LyT Ly(MRT >= 0 ? MRT : D->n_rows);
-    const int MR = Ly.MR, MRP = Ly.MRP, NRC = Ly.NRC, NRT = Ly.NRT;
+    const int MR = Ly.MR, MRP = Ly.MRP, NRC = Ly.NRC;
     const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;
     double* const ws = ws_all + (size_t)b * Ly.per_instance(N);
     const double dt = D->dt, cB = 0.5 * dt * dt;
+    const int img_pf = Ly.nIMG >> 6;   // 16-byte loads per lane that cover the image (<= IMG_PF)
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
-    constexpr int O_TD = IMG_MAX, O_GD = O_TD + NZ * NQP, O_D = O_GD + NQ * MRP_MAX, O_E = O_D + 32, O_LAM = O_E + 32,
+    constexpr int O_TD = IMG_MAX, O_GD = O_TD + NZ * NQP, O_D = O_GD + NQ * MRP_MAX, O_E = O_D + NL, O_LAM = O_E + NL,
                   O_G = O_LAM + qp_even_c(NQ * NQ), O_WT = O_G + NQ * WS2, O_HXX = O_WT + (NX + 1) * NQP, O_PA = O_HXX + NX * NX,
                   O_PB2 = O_PA + NX * NX, O_PVA = O_PB2 + NX * NX, O_PVB = O_PVA + NX, O_PB = O_PVB + NX, O_Q = O_PB + NX,
                   O_ZU = O_Q + NX, O_XB = O_ZU + NQP, O_RHO = O_XB + 2 * NX, O_WV = O_RHO + NQP, HALF_D = O_WV + NQP;
@@ -562,6 +532,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const double* xb0 = xg + (size_t)b * (N + 1) * NX;
     const double* ub0 = ug + (size_t)b * N * NU;
     const double dx0_reg = hl < NX ? x0[(size_t)b * NX + hl] - xb0[hl] : 0.0;
+    // lane roles (clamped indices keep every load unconditional)
+    const int hl_u = hl < NQ ? hl : NQ - 1;                          // control owned / aliased by this lane
+    const int hl_x = hl < NX ? hl : NX - 1;                          // state component
+    const int hl_c = hl >= NX && hl < NX + NRC ? hl - NX : 0;        // general row
+    const int hl_px = hl >= NU && hl < NZ ? hl - NU : 0;             // state component of the lanes NU..NZ-1
+    const bool soft_lane = (hl == rNN);
 
     // ---- Cholesky factor in registers (every lane redundantly): strictly-lower entries + inverse diagonal -----------------
     double Lr[NQ][NQ], Linv[NQ];
@@ -634,81 +610,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         if (mu <= tol && rho_lin * R0 <= tol) { st_code = 0; break; }
 
         // ---------------- sweep B1: apply the pending step, factorise H + C^T D C, predictor costate ----------------------
+        // (alpha = 0 and zero directions before the first step: the update is applied unconditionally)
         double mu_new = 0.0;
         {
             dbl2 img[IMG_PF];
-            QpRow rs{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
-            QpDir rd{0.0, 0.0, 0.0, 0.0, 0.0};
-            dbl2 slb0{0.0, 0.0}, slb1{0.0, 0.0};
-            double zc = 0.0, znc = 0.0;
+            QpRow rs;
+            QpDir rd;
+            dbl2 slb;
+            double zc, znc;
             auto load_b1 = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
 #pragma unroll
-                for (int j = 0; j < IMG_PF; j++) {
-                    const int i = hl + 32 * j;
-                    if (i < (Ly.nIMG >> 1)) img[j] = s2[i];
-                }
-                if (hl < NRT) {
-                    rs.lo = w[Ly.oLO + hl]; rs.hi = w[Ly.oHI + hl];
-                    rs.tl = w[Ly.oTL + hl]; rs.tu = w[Ly.oTU + hl];
-                    rs.ll = w[Ly.oLL + hl]; rs.lu = w[Ly.oLU + hl];
-                    rd.dtl = w[Ly.oDTL + hl]; rd.dtu = w[Ly.oDTU + hl];
-                    rd.dll = w[Ly.oDLL + hl]; rd.dlu = w[Ly.oDLU + hl];
-                }
-                slb0 = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                slb1 = *reinterpret_cast<const dbl2*>(w + Ly.oSL + 2);
-                if (hl < NZ) { zc = w[Ly.oZ + hl]; znc = w[Ly.oZN + hl]; }
+                for (int j = 0; j < IMG_PF; j++)
+                    if (j < img_pf) img[j] = s2[hl + 32 * j];
+                const double* wr = w + Ly.oLO + hl;
+                rs.lo = wr[0]; rs.hi = wr[NL]; rs.tl = wr[2 * NL]; rs.tu = wr[3 * NL]; rs.ll = wr[4 * NL]; rs.lu = wr[5 * NL];
+                rd.dtl = wr[7 * NL]; rd.dtu = wr[8 * NL]; rd.dll = wr[9 * NL]; rd.dlu = wr[10 * NL];
+                slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
+                zc = w[Ly.oZ + hl];
+                znc = w[Ly.oZN + hl];
             };
-            load_b1(N);
-            for (int k = N; k >= 0; k--) {
+            auto stage_b1 = [&](int k, auto last_tag) {
+                constexpr bool last = decltype(last_tag)::value;
                 asm volatile("; QPMARK B1_BEGIN");
-                const bool last = (k == N);
                 double* w = ws + (size_t)k * Ly.stride;
-                // -- image -> LDS; rows: (apply step) + barrier weights + predictor coefficients, all in the owner's registers
+                // -- image -> LDS; rows: apply the step, barrier weights, predictor coefficients -- all in the owner's registers
                 {
                     dbl2* d2 = reinterpret_cast<dbl2*>(sIMG);
 #pragma unroll
-                    for (int j = 0; j < IMG_PF; j++) {
-                        const int i = hl + 32 * j;
-                        if (i < (Ly.nIMG >> 1)) d2[i] = img[j];
-                    }
+                    for (int j = 0; j < IMG_PF; j++)
+                        if (j < img_pf) d2[hl + 32 * j] = img[j];
                 }
-                const double wsoft = slb1.x;
-                const bool bflag = !last && slb1.y != 0.0;
-                if (hl < NRT) {
-                    const bool soft = (hl == rNN) && wsoft >= 0.0;
-                    double sl = slb0.x;
-                    if (pending) {
-                        if (rs.lo > -QP_ABSENT) {
-                            rs.tl += alpha * rd.dtl;
-                            rs.ll += alpha * rd.dll;
-                            if (soft) { sl += alpha * slb0.y; w[Ly.oSL] = sl; }
-                        }
-                        if (rs.hi < QP_ABSENT) {
-                            rs.tu += alpha * rd.dtu;
-                            rs.lu += alpha * rd.dlu;
-                        }
-                        w[Ly.oTL + hl] = rs.tl; w[Ly.oLL + hl] = rs.ll;
-                        w[Ly.oTU + hl] = rs.tu; w[Ly.oLU + hl] = rs.lu;
-                    }
+                const double wsoft = slb.x;
+                const bool bflag = !last && slb.y != 0.0;
+                {
+                    const bool soft = soft_lane && wsoft >= 0.0;
+                    rs.tl += alpha * rd.dtl; rs.ll += alpha * rd.dll;
+                    rs.tu += alpha * rd.dtu; rs.lu += alpha * rd.dlu;
+                    double* wr = w + Ly.oLO + hl;
+                    wr[2 * NL] = rs.tl; wr[3 * NL] = rs.tu; wr[4 * NL] = rs.ll; wr[5 * NL] = rs.lu;
                     double Dr;
-                    sE[hl] = qp_row_coeff(rs, soft, wsoft, sl, 0.0, 0.0, 0.0, &Dr);
+                    sE[hl] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
                     sD[hl] = Dr;
-                    mu_new += qp_row_comp(rs, soft, wsoft, sl);
+                    mu_new += qp_row_comp(rs, soft, wsoft);
                 }
-                if (pending && hl < NZ) { zc += alpha * (znc - zc); w[Ly.oZ + hl] = zc; }
+                zc += alpha * (znc - zc);
+                w[Ly.oZ + hl] = zc;
                 lds_fence();
                 QPT(0);
-                if (k > 0) load_b1(k - 1);
+                load_b1(k > 0 ? k - 1 : 0);
                 // -- P b, and the rows scaled by their barrier weights
-                if (!last && hl < NX) {
+                {
                     double a = 0.0;
-                    if (bflag) {
+                    if (bflag && hl < NX) {
 #pragma unroll
                         for (int jx = 0; jx < NX; jx++) a = fma(Pc[hl * NX + jx], sB[jx], a);
                     }
-                    sPB[hl] = a;
+                    if (hl < NX) sPB[hl] = a;
                     w[Ly.oPB + hl] = a;
                 }
                 for (int el = hl; el < NZ * NQP; el += 32) {
@@ -787,11 +746,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 QPT(2);
                 if (!last) {
                     if (!chol_from_lds(sLam)) broke = true;
-                    // one column per lane: [W | w] = L^-1 [G | rho], [K | k] = L^-T [W | w]; NQ more lanes invert L
-                    if (hl <= NX + NQ) {
+                    // one column per lane: [W | w] = L^-1 [G | rho], [K | k] = L^-T [W | w]; lanes LC0.. do the same to the
+                    // unit vectors, which leaves L^-1 next to W; every lane stores its column (row stride NL)
+                    {
                         double col[NQ];
+                        const int cg = hl <= NX ? hl : NX;
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) col[i] = hl <= NX ? sG[i * WS2 + hl] : (i == hl - NX - 1 ? 1.0 : 0.0);
+                        for (int i = 0; i < NQ; i++) col[i] = hl <= NX ? sG[i * WS2 + cg] : (i == hl - LC0 ? 1.0 : 0.0);
 #pragma unroll
                         for (int i = 0; i < NQ; i++) {
                             double v = col[i];
@@ -801,22 +762,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         }
                         if (hl <= NX) {
 #pragma unroll
-                            for (int i = 0; i < NQ; i++) { sWT[hl * NQP + i] = col[i]; w[Ly.oW + i * WS2 + hl] = col[i]; }
-                            double kc[NQ];
-#pragma unroll
-                            for (int i = NQ - 1; i >= 0; i--) {
-                                double v = col[i];
-#pragma unroll
-                                for (int t = i + 1; t < NQ; t++) v = fma(-Lr[t][i], kc[t], v);
-                                kc[i] = v * Linv[i];
-                            }
-#pragma unroll
-                            for (int i = 0; i < NQ; i++) w[Ly.oK + i * WS2 + hl] = kc[i];
-                        } else {
-                            const int j = hl - NX - 1;
-#pragma unroll
-                            for (int i = 0; i < NQ; i++) w[Ly.oLI + i * NQP + j] = col[i];
+                            for (int i = 0; i < NQ; i++) sWT[hl * NQP + i] = col[i];
                         }
+#pragma unroll
+                        for (int i = 0; i < NQ; i++) w[Ly.oW + i * NL + hl] = col[i];
+#pragma unroll
+                        for (int i = NQ - 1; i >= 0; i--) {
+                            double v = col[i];
+#pragma unroll
+                            for (int t = i + 1; t < NQ; t++) v = fma(-Lr[t][i], col[t], v);
+                            col[i] = v * Linv[i];
+                        }
+#pragma unroll
+                        for (int i = 0; i < NQ; i++) w[Ly.oK + i * NL + hl] = col[i];
                     }
                     lds_fence();
                     QPT(3);
@@ -853,7 +811,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 }
                 QPT(5);
                 asm volatile("; QPMARK B1_END");
-            }
+            };
+            load_b1(N);
+            stage_b1(N, std::true_type{});
+#pragma unroll 1
+            for (int k = N - 1; k >= 0; k--) stage_b1(k, std::false_type{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (half_max(broke ? 1.0 : 0.0) > 0.0) { st_code = 4; pending = false; break; }
@@ -865,64 +827,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 
         // ---------------- forward sweeps: roll-out through the stored gains, ratio tests ---------------------------------------
         // F1 (predictor): c.z_aff of every row is stored for B2 / F2.   F2 (corrector): z+ and the row directions are stored.
-        auto sweep_f = [&](auto corr_tag, double* amin_out, double* S1_out, double* S2_out) {
+        // Returns the largest ratio -d/v over all slacks and multipliers (its reciprocal is the step to the boundary).
+        auto sweep_f = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
-            double amin = 1e300, S1 = 0.0, S2 = 0.0;
+            double rr = 0.0, S1 = 0.0, S2 = 0.0;
             dbl2 Kr[WS2 / 2], Cr[NZP / 2];
-            QpRow rs{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
-            dbl2 slb0{0.0, 0.0}, slb1{0.0, 0.0};
-            double bi = 0.0, czar = 0.0;
+            QpRow rs;
+            dbl2 slb;
+            double bi, czar = 0.0;
             double *xb = sIMG + O_XB, *xn = sIMG + O_XB + NX;
             auto load_k = [&](int k) {
-                const double* w = ws + (size_t)k * Ly.stride;
-                if (hl < NQ) {
-                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oK + hl * WS2);
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(ws + (size_t)k * Ly.stride + Ly.oK + hl_u * NL);
 #pragma unroll
-                    for (int j = 0; j < WS2 / 2; j++) Kr[j] = s2[j];
-                }
+                for (int j = 0; j < WS2 / 2; j++) Kr[j] = s2[j];
             };
             auto load_c = [&](int k) {
-                const double* w = ws + (size_t)k * Ly.stride;
-                if (hl >= NX && hl < NRT) {
-                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oC + (hl - NX) * NZP);
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(ws + (size_t)k * Ly.stride + Ly.oC + hl_c * NZP);
 #pragma unroll
-                    for (int j = 0; j < NZP / 2; j++) Cr[j] = s2[j];
-                }
+                for (int j = 0; j < NZP / 2; j++) Cr[j] = s2[j];
             };
             auto load_r = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
-                if (hl < NRT) {
-                    rs.lo = w[Ly.oLO + hl]; rs.hi = w[Ly.oHI + hl];
-                    rs.tl = w[Ly.oTL + hl]; rs.tu = w[Ly.oTU + hl];
-                    rs.ll = w[Ly.oLL + hl]; rs.lu = w[Ly.oLU + hl];
-                    if (CORR) czar = w[Ly.oCZA + hl];
-                }
-                slb0 = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                slb1 = *reinterpret_cast<const dbl2*>(w + Ly.oSL + 2);
+                const double* wr = w + Ly.oLO + hl;
+                rs.lo = wr[0]; rs.hi = wr[NL]; rs.tl = wr[2 * NL]; rs.tu = wr[3 * NL]; rs.ll = wr[4 * NL]; rs.lu = wr[5 * NL];
+                if (CORR) czar = wr[6 * NL];
+                slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
             };
             if (hl < NX) xb[hl] = dx0_reg;
             load_k(0);
-            if (hl < NX) bi = ws[Ly.oIMG + Ly.iB + hl];
+            bi = ws[Ly.oIMG + Ly.iB + hl_x];
             load_c(0);
             load_r(0);
             lds_fence();
+#pragma unroll 1
             for (int k = 0; k <= N; k++) {
                 if (CORR) asm volatile("; QPMARK F2_BEGIN"); else asm volatile("; QPMARK F1_BEGIN");
                 const bool last = (k == N);
+                const int kn = k < N ? k + 1 : N;          // the end stage re-loads itself: every load stays unconditional
+                const int kk = kn < N ? kn : N - 1;        // (there are no gains at the end stage)
                 double* w = ws + (size_t)k * Ly.stride;
                 // u_i = -(K_i x + k_i): one lane per control, x broadcast from LDS
-                if (hl < NQ) {
-                    double ui = 0.0;
-                    if (!last) {
-                        const double* kr = reinterpret_cast<const double*>(Kr);
-                        double a = kr[NX];
+                {
+                    const double* kr = reinterpret_cast<const double*>(Kr);
+                    double a = kr[NX];
 #pragma unroll
-                        for (int j = 0; j < NX; j++) a = fma(kr[j], xb[j], a);
-                        ui = -a;
-                    }
-                    sZU[hl] = ui;
+                    for (int j = 0; j < NX; j++) a = fma(kr[j], xb[j], a);
+                    if (hl < NQ) sZU[hl] = last ? 0.0 : -a;
                 }
-                if (k + 1 < N) load_k(k + 1);
+                load_k(kk);
                 lds_fence();
                 QPT(CORR ? 10 : 6);
                 // x+ = A x + B u + b
@@ -931,50 +883,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     const double u = sZU[i];
                     xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi : xb[hl] + dt * u + bi;
                 }
-                if (k + 1 < N && hl < NX) bi = w[Ly.stride + Ly.oIMG + Ly.iB + hl];
+                bi = ws[(size_t)kk * Ly.stride + Ly.oIMG + Ly.iB + hl_x];
                 // rows: c.z for the trial point, directions, ratio test
-                if (hl < NRT) {
-                    double cz;
-                    if (hl < NX) cz = xb[hl];
-                    else {
-                        const double* cr = reinterpret_cast<const double*>(Cr);
-                        double a = 0.0;
+                {
+                    const double* cr = reinterpret_cast<const double*>(Cr);
+                    double a = 0.0;
 #pragma unroll
-                        for (int c = 0; c < NU; c++) a = fma(cr[c], sZU[c], a);
+                    for (int c = 0; c < NU; c++) a = fma(cr[c], sZU[c], a);
 #pragma unroll
-                        for (int c = 0; c < NX; c++) a = fma(cr[NU + c], xb[c], a);
-                        cz = a;
-                    }
-                    const double wsoft = slb1.x, sl = slb0.x;
-                    const bool soft = (hl == rNN) && wsoft >= 0.0;
+                    for (int c = 0; c < NX; c++) a = fma(cr[NU + c], xb[c], a);
+                    const double cz = hl < NX ? xb[hl_x] : a;
+                    load_c(kn);
+                    const double wsoft = slb.x;
+                    const bool soft = soft_lane && wsoft >= 0.0;
+                    double* wr = w + Ly.oLO + hl;
                     if (!CORR) {
-                        const QpDir d = qp_row_dir(rs, soft, wsoft, sl, cz, 0.0, 0.0, 0.0);
-                        amin = fmin(amin, qp_row_ratio(rs, soft, wsoft, sl, d, &S1, &S2));
-                        w[Ly.oCZA + hl] = cz;
+                        qp_row_dir(rs, soft, wsoft, cz, 0.0, 0.0, 0.0, &rr, &S1, &S2);
+                        wr[6 * NL] = cz;
                     } else {
-                        const QpDir d = qp_row_dir(rs, soft, wsoft, sl, cz, sigmu, corr_w, czar);
-                        amin = fmin(amin, qp_row_ratio(rs, soft, wsoft, sl, d, &S1, &S2));
-                        w[Ly.oDTL + hl] = d.dtl; w[Ly.oDTU + hl] = d.dtu;
-                        w[Ly.oDLL + hl] = d.dll; w[Ly.oDLU + hl] = d.dlu;
-                        if (soft) w[Ly.oSL + 1] = d.dsl;
+                        const QpDir d = qp_row_dir(rs, soft, wsoft, cz, sigmu, corr_w, czar, &rr, &S1, &S2);
+                        wr[7 * NL] = d.dtl; wr[8 * NL] = d.dtu; wr[9 * NL] = d.dll; wr[10 * NL] = d.dlu;
+                        w[Ly.oZN + hl] = hl < NU ? sZU[hl_u] : xb[hl_px];
                     }
+                    load_r(kn);
                 }
-                if (CORR && hl < NZ) w[Ly.oZN + hl] = hl < NU ? sZU[hl] : xb[hl - NU];
-                if (k < N) { load_c(k + 1); load_r(k + 1); }
                 lds_fence();
                 { double* t = xb; xb = xn; xn = t; }
                 QPT(CORR ? 11 : 7);
                 if (CORR) asm volatile("; QPMARK F2_END"); else asm volatile("; QPMARK F1_END");
             }
-            *amin_out = half_min(amin);
+            *rr_out = half_max(rr);
             *S1_out = half_sum(S1);
             *S2_out = half_sum(S2);
         };
 
-        double a_aff, S1, S2;
-        sweep_f(std::false_type{}, &a_aff, &S1, &S2);
+        double rr_aff, S1, S2;
+        sweep_f(std::false_type{}, &rr_aff, &S1, &S2);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        a_aff = fmin(1.0, a_aff);
+        const double a_aff = rr_aff > 1.0 ? 1.0 / rr_aff : 1.0;
         const double mu_aff = (mu * (double)m_comp + a_aff * S1 + a_aff * a_aff * S2) * inv_m;
         double sigma = mu_aff / mu;
         sigma = fmin(sigma * sigma * sigma, 0.3);  // centring cap (see oracle): halves the iteration tail
@@ -982,117 +928,112 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         // safeguard against Mehrotra cycling (see oracle): damp the second-order term when the affine step is blocked early
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
 
-        // ---------------- sweep B2: corrector gradient and costate recursion with the stored factors ------------------------
+        // ---------------- sweep B2: corrector gradient and costate recursion with the stored gains --------------------------
         {
-            QpRow rs{0.0, 0.0, 1.0, 1.0, 0.0, 0.0};
-            dbl2 slb0{0.0, 0.0}, slb1{0.0, 0.0};
-            double czar = 0.0, pbr = 0.0, gzr = 0.0;
+            QpRow rs;
+            dbl2 slb;
+            double czar, pbr, gzr;
             double Cc[NRC_MAX], LIr[NQP], LIc[NQ], Wc[NQ];
             auto load_r = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
-                if (hl < NRT) {
-                    rs.lo = w[Ly.oLO + hl]; rs.hi = w[Ly.oHI + hl];
-                    rs.tl = w[Ly.oTL + hl]; rs.tu = w[Ly.oTU + hl];
-                    rs.ll = w[Ly.oLL + hl]; rs.lu = w[Ly.oLU + hl];
-                    czar = w[Ly.oCZA + hl];
-                }
-                slb0 = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                slb1 = *reinterpret_cast<const dbl2*>(w + Ly.oSL + 2);
-                if (hl < NX && k < N) pbr = w[Ly.oPB + hl];
+                const double* wr = w + Ly.oLO + hl;
+                rs.lo = wr[0]; rs.hi = wr[NL]; rs.tl = wr[2 * NL]; rs.tu = wr[3 * NL]; rs.ll = wr[4 * NL]; rs.lu = wr[5 * NL];
+                czar = wr[6 * NL];
+                slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
+                pbr = w[Ly.oPB + hl];
             };
             auto load_g = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
-                if (hl < NZ) {
 #pragma unroll
-                    for (int r = 0; r < NRC_MAX; r++)
-                        if (r < NRC) Cc[r] = w[Ly.oC + r * NZP + hl];
-                    gzr = w[Ly.oIMG + Ly.iGZ + hl];
-                }
+                for (int r = 0; r < NRC_MAX; r++)
+                    if (r < NRC) Cc[r] = w[Ly.oC + r * NZP + hl];   // (lanes >= NZ read into the next block: unused)
+                gzr = w[Ly.oIMG + Ly.iGZ + (hl < NZ ? hl : 0)];
             };
-            auto load_f = [&](int k) {  // factors of stage k < N
+            auto load_f = [&](int k) {  // factors of stage k < N: row and column of L^-1, column of W
                 const double* w = ws + (size_t)k * Ly.stride;
-                if (hl < NQ) {
-                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oLI + hl * NQP);
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oW + hl_u * NL + LC0);
 #pragma unroll
-                    for (int j = 0; j < NQP / 2; j++) { const dbl2 v = s2[j]; LIr[2 * j] = v.x; LIr[2 * j + 1] = v.y; }
+                for (int j = 0; j < NQP / 2; j++) { const dbl2 v = s2[j]; LIr[2 * j] = v.x; LIr[2 * j + 1] = v.y; }
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) LIc[j] = w[Ly.oLI + j * NQP + hl];
-                } else if (hl >= NU && hl < NZ) {
-#pragma unroll
-                    for (int t = 0; t < NQ; t++) Wc[t] = w[Ly.oW + t * WS2 + hl - NU];
-                }
+                for (int t = 0; t < NQ; t++) { LIc[t] = w[Ly.oW + t * NL + LC0 + hl_u]; Wc[t] = w[Ly.oW + t * NL + hl_px]; }
             };
-            load_r(N);
-            load_g(N);
-            if (N > 0) load_f(N - 1);
-            for (int k = N; k >= 0; k--) {
+            auto stage_b2 = [&](int k, auto last_tag) {
+                constexpr bool last = decltype(last_tag)::value;
                 asm volatile("; QPMARK B2_BEGIN");
-                const bool last = (k == N);
                 double* w = ws + (size_t)k * Ly.stride;
-                if (hl < NRT) {
-                    const double wsoft = slb1.x, sl = slb0.x;
-                    const bool soft = (hl == rNN) && wsoft >= 0.0;
+                const int kp = k > 0 ? k - 1 : 0;
+                {
+                    const double wsoft = slb.x;
+                    const bool soft = soft_lane && wsoft >= 0.0;
                     double Dr;
-                    sE[hl] = qp_row_coeff(rs, soft, wsoft, sl, sigmu, corr_w, czar, &Dr);
+                    sE[hl] = qp_row_coeff(rs, soft, wsoft, sigmu, corr_w, czar, &Dr);
                 }
                 if (!last && hl < NX) sQ[hl] = pvc[hl] + pbr;   // p_{k+1} + P b
-                if (k > 0) load_r(k - 1);
+                load_r(kp);
                 lds_fence();
                 QPT(8);
                 double ghx = 0.0;
-                if (hl < NZ) {
+                {
                     double gh = gzr;
 #pragma unroll
                     for (int r = 0; r < NRC_MAX; r++)
                         if (r < NRC) gh = fma(Cc[r], sE[NX + r], gh);
                     if (hl >= NU) gh += sE[hl - NU];
                     if (last) {
-                        if (hl >= NU) pvn[hl - NU] = gh;
+                        if (hl >= NU && hl < NZ) pvn[hl - NU] = gh;
                     } else if (hl < NU) {
                         sRho[hl] = gh + cB * sQ[hl] + dt * sQ[NQ + hl];
                     } else {
                         ghx = gh;
                     }
                 }
-                if (k > 0) load_g(k - 1);
+                load_g(kp);
                 lds_fence();
                 if (!last) {
                     // wv = L^-1 rho ; k = L^-T wv ; p_k = gh_x + A^T (p_{k+1} + P b) - W^T wv
-                    if (hl < NQ) {
+                    {
                         double v = 0.0;
 #pragma unroll
                         for (int j = 0; j < NQ; j++) v = fma(LIr[j], sRho[j], v);
-                        sWv[hl] = v;
+                        if (hl < NQ) sWv[hl] = v;
                     }
                     lds_fence();
-                    if (hl < NQ) {
-                        double v = 0.0;
+                    double kv = 0.0, pv = 0.0;
 #pragma unroll
-                        for (int j = 0; j < NQ; j++) v = fma(LIc[j], sWv[j], v);
-                        w[Ly.oK + hl * WS2 + NX] = v;
-                    } else if (k > 0 && hl >= NU && hl < NZ) {
-                        const int i = hl - NU;
-                        double v = ghx + (i < NQ ? sQ[i] : dt * sQ[i - NQ] + sQ[i]);
-#pragma unroll
-                        for (int t = 0; t < NQ; t++) v = fma(-Wc[t], sWv[t], v);
-                        pvn[i] = v;
+                    for (int j = 0; j < NQ; j++) {
+                        const double wj = sWv[j];
+                        kv = fma(LIc[j], wj, kv);
+                        pv = fma(Wc[j], wj, pv);
                     }
+                    double* dst = hl < NQ ? w + Ly.oK + hl * NL + NX : w + Ly.oDUM + hl;
+                    *dst = kv;
+                    if (k > 0 && hl >= NU && hl < NZ) {
+                        const int i = hl - NU;
+                        pvn[i] = ghx + (i < NQ ? sQ[i] : dt * sQ[i - NQ] + sQ[i]) - pv;
+                    }
+                    load_f(kp);
                 }
-                if (!last && k > 0) load_f(k - 1);   // (the factors of stage N-1 are already in flight during stage N)
                 lds_fence();
                 if (last || k > 0) { double* t2 = pvc; pvc = pvn; pvn = t2; }
                 QPT(9);
                 asm volatile("; QPMARK B2_END");
-            }
+            };
+            load_r(N);
+            load_g(N);
+            load_f(N > 0 ? N - 1 : 0);
+            stage_b2(N, std::true_type{});
+#pragma unroll 1
+            for (int k = N - 1; k >= 0; k--) stage_b2(k, std::false_type{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
         // ---------------- sweep F2: corrector roll-out and step length --------------------------------------------------------
-        double a_max, S1c, S2c;
-        sweep_f(std::true_type{}, &a_max, &S1c, &S2c);
+        double rr_max, S1c, S2c;
+        sweep_f(std::true_type{}, &rr_max, &S1c, &S2c);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // fraction to the boundary (see oracle): 0.995, approaching 1 with the complementarity (cap 0.9999) when the step is
         // within 1% of the full Newton step; an earlier-blocked step keeps the classical margin to stay centred
+        const double a_max = rr_max > 0.0 ? 1.0 / rr_max : 1e300;
         const double tau_k = a_max >= 0.99 ? fmin(0.9999, fmax(QP_FTB, 1.0 - mu)) : QP_FTB;
         alpha = fmin(1.0, tau_k * a_max);
         if (!(alpha == alpha)) { st_code = 4; break; }
@@ -1108,19 +1049,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // ---- full SQP step (FIXED_STEP, parser.py:139), applying the last IPM step if it is still pending -------------------
     bool bad = false;
     const double a_fin = pending ? alpha : 0.0;
+#pragma unroll 4
     for (int k = 0; k <= N; k++) {
-        const double* zk = ws + (size_t)k * Ly.stride + Ly.oZ;
-        const double* zn = ws + (size_t)k * Ly.stride + Ly.oZN;
-        if (hl < NX) {
-            const double z = zk[NU + hl];
-            const double v = xb0[(size_t)k * NX + hl] + z + a_fin * (zn[NU + hl] - z);
-            x_out[((size_t)b * (N + 1) + k) * NX + hl] = v;
-            bad |= !(v == v);
-        }
-        if (k < N && hl < NU) {
-            const double z = zk[hl];
-            const double v = ub0[(size_t)k * NU + hl] + z + a_fin * (zn[hl] - z);
-            u_out[((size_t)b * N + k) * NU + hl] = v;
+        const double* w = ws + (size_t)k * Ly.stride;
+        const double z = w[Ly.oZ + hl], zn = w[Ly.oZN + hl];
+        const int ku = k < N ? k : N - 1;
+        const double base = hl < NU ? ub0[(size_t)ku * NU + hl_u] : xb0[(size_t)k * NX + hl_px];
+        const double v = base + z + a_fin * (zn - z);
+        if (hl < NU) {
+            if (k < N) { u_out[((size_t)b * N + k) * NU + hl] = v; bad |= !(v == v); }
+        } else if (hl < NZ) {
+            x_out[((size_t)b * (N + 1) + k) * NX + hl - NU] = v;
             bad |= !(v == v);
         }
     }
