@@ -23,8 +23,9 @@
 //   * the factorisation stores the gain in closed form (K = Lambda^-1 G, k; W = L^-1 G and L^-1 for the costate -- the
 //     symmetric two-step form keeps the corrector solve as accurate as substitution), so the three light sweeps are
 //     lane-parallel matrix-vector products separated by wave-scope LDS fences (no s_barrier, no vmcnt drain);
-//   * every vector-memory instruction of a stage is unconditional and straight-line (row arrays padded to 32 lanes with
-//     "absent" rows, lane and stage indices clamped instead of branched on, the horizon's end stage peeled off): gfx9
+//   * every vector-memory instruction of a stage is unconditional and straight-line (lanes beyond an array's length
+//     duplicate its last entry -- same loads, same arithmetic, same stores to the same address -- stage indices are
+//     clamped instead of branched on, the horizon's end stage is peeled off): gfx9
 //     counts loads and stores in ONE in-order vmcnt, and the compiler can only wait for "all but the n youngest" when
 //     n is the same on every path -- a single conditional load otherwise turns each wait into vmcnt(0) and serialises
 //     the stage on the loads it has just issued for the next one.
@@ -51,15 +52,14 @@ constexpr int qp_even_c(int n) { return (n + 1) & ~1; }
 template <int NQ> struct QpLayout {
     static constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ;
     static constexpr int NZP = qp_even_c(NZ), NQP = qp_even_c(NQ), WS2 = qp_even_c(NX + 1);
-    static constexpr int NL = 32;       // lanes of a half-wave = padded length of every per-row / per-variable array
-    static constexpr int LC0 = WS2;     // first column of L^-1 inside the rows of W
+    static constexpr int LC0 = WS2;                    // first column of L^-1 inside the rows of W
+    static constexpr int KS = qp_even_c(LC0 + NQ);     // row stride of the gain blocks = lanes that own a column
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
-    // static blocks
-    int oC, oLO, oHI, oIMG;
-    // dynamic blocks
-    int oTL, oTU, oLL, oLU, oCZA, oDTL, oDTU, oDLL, oDLU, oSL, oZ, oZN, oK, oW, oPB, oDUM, oPART;
+    int oC, oIMG, oK, oW, oSL;                                  // 16-byte aligned blocks
+    int oLO, oHI, oTL, oTU, oLL, oLU, oCZA, oCZN;               // one entry per row, NRT each, contiguous
+    int oZ, oZN, oPB, oPART;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
         MR = n_rows;
@@ -74,29 +74,25 @@ template <int NQ> struct QpLayout {
         iGZ = i; i += NZP;                 // cost gradient
         iB = i; i += NX;                   // dynamics defect
         iSC = i; i += 4;                   // [Huu diagonal, LM on the v diagonal, soft weight, b != 0]
-        nIMG = (i + 63) & ~63;             // whole 16-byte loads for all 32 lanes
+        nIMG = i;                          // (even)
         int o = 0;
         oC = o; o += NRC * NZP;            // general rows, row-major (F: rows, B2: columns)
-        oLO = o; o += NL;                  // rows >= NRT are "absent" on both sides
-        oHI = o; o += NL;
-        oTL = o; o += NL;
-        oTU = o; o += NL;                  // (the soft row has no upper side: its slack lives here)
-        oLL = o; o += NL;
-        oLU = o; o += NL;
-        oCZA = o; o += NL;                 // c . z_aff of every row (F1 -> B2, F2)
-        oDTL = o; o += NL;                 // step directions of every row (F2 -> B1)
-        oDTU = o; o += NL;
-        oDLL = o; o += NL;
-        oDLU = o; o += NL;
-        oSL = o; o += 2;                   // [soft weight, b != 0]
-        oZ = o; o += NL;
-        oZN = o; o += NL;
-        oK = o; o += NQ * NL;              // gain rows [K_i | k_i | ...]            = L^-T L^-1 [G | rho | I]
-        oW = o; o += NQ * NL;              // half-way rows [W_i | w_i | . | L^-1_i | .] = L^-1 [G | rho | I]
-        oPB = o; o += NL;                  // P b
-        oDUM = o; o += NL;                 // landing zone of the lanes that have nothing to store
-        oPART = o; o += 4;                 // setup partials [R0, sum lambda t, count]
         oIMG = o; o += nIMG;
+        oK = o; o += NQ * KS;              // gain rows [K_i | k_i | ...]                = L^-T L^-1 [G | rho | I]
+        oW = o; o += NQ * KS;              // half-way rows [W_i | w_i | . | L^-1_i | .] = L^-1 [G | rho | I]
+        oSL = o; o += 2;                   // [soft weight, b != 0]
+        oLO = o; o += NRT;
+        oHI = o; o += NRT;
+        oTL = o; o += NRT;
+        oTU = o; o += NRT;                 // (the soft row has no upper side: its slack lives here)
+        oLL = o; o += NRT;
+        oLU = o; o += NRT;
+        oCZA = o; o += NRT;                // c . z_aff of every row (F1 -> B2, F2, B1)
+        oCZN = o; o += NRT;                // c . z+    of every row (F2 -> B1)
+        oZ = o; o += NZ;
+        oZN = o; o += NZ;
+        oPB = o; o += NX;                  // P b
+        oPART = o; o += 4;                 // setup partials [R0, sum lambda t, count]
         stride = qp_even_c(o);
     }
     __host__ __device__ size_t per_instance(int N) const { return (size_t)stride * (N + 1); }
@@ -257,7 +253,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
                                                  const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
                                                  long bnd_stride) {
     using LyT = QpLayout<NQ>;
-    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, NL = LyT::NL;
+    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, NL = 32;
     constexpr int MAXRC = NQ + (MRT >= 0 ? MRT : SMPC_MAX_ROWS) + 1;
     constexpr int EV_D = (int)(sizeof(smpc_node_eval) / sizeof(double)), EV_PAD = qp_even_c(EV_D);
     const int hl = threadIdx.x & 31, half = threadIdx.x >> 5;
@@ -361,8 +357,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
 
     // ---- static blocks out ---------------------------------------------------------------------------------------------
     for (int el = hl; el < NRC * NZP; el += 32) w[Ly.oC + el] = sC[el];
-    w[Ly.oLO + hl] = sLO[hl];
-    w[Ly.oHI + hl] = sHI[hl];
+    if (hl < NRT) { w[Ly.oLO + hl] = sLO[hl]; w[Ly.oHI + hl] = sHI[hl]; }
     double* img = w + Ly.oIMG;
     for (int el = hl; el < NZ * NQP; el += 32) {
         const int c = el / NQP, r = el - c * NQP;
@@ -383,7 +378,6 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         const double huu = (reach && !last ? cs * 2.0 * D->R : 0.0) + lm;
         img[Ly.iSC + hl] = hl == 0 ? huu : (hl == 1 ? lm : (hl == 2 ? wsoft : bflag));
     }
-    for (int el = Ly.iSC + 4 + hl; el < Ly.nIMG; el += 32) img[el] = 0.0;
 
     // ---- initial slacks / multipliers ----------------------------------------------------------------------------------
     double r0_loc = 0.0, mu_acc = 0.0;
@@ -419,15 +413,16 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
                 mu_acc += lu * tu;
             }
         }
-        w[Ly.oTL + r] = tl; w[Ly.oLL + r] = ll; w[Ly.oTU + r] = tu; w[Ly.oLU + r] = lu;
-        w[Ly.oCZA + r] = 0.0;
-        w[Ly.oDTL + r] = 0.0; w[Ly.oDTU + r] = 0.0; w[Ly.oDLL + r] = 0.0; w[Ly.oDLU + r] = 0.0;
+        if (r < NRT) {
+            w[Ly.oTL + r] = tl; w[Ly.oLL + r] = ll; w[Ly.oTU + r] = tu; w[Ly.oLU + r] = lu;
+            w[Ly.oCZA + r] = 0.0;
+            w[Ly.oCZN + r] = 0.0;
+        }
         sE[r] = -(ll - lu);
     }
     if (hl < 2) w[Ly.oSL + hl] = hl == 0 ? wsoft : bflag;
-    w[Ly.oZ + hl] = sZ0[hl];
-    w[Ly.oZN + hl] = sZ0[hl];
-    w[Ly.oPB + hl] = 0.0;
+    if (hl < NZ) { w[Ly.oZ + hl] = sZ0[hl]; w[Ly.oZN + hl] = sZ0[hl]; }
+    if (hl < NX) w[Ly.oPB + hl] = 0.0;
     lds_fence();
     // stationarity residual at the initial point (pi = 0): g - C^T (ll - lu); dx_0 does not enter (no cost cross term)
     if (hl < NZ && !(k == 0 && hl >= NU) && !(last && hl < NU)) {
@@ -459,15 +454,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     int32_t* __restrict__ status, int32_t* __restrict__ qp_iter, const int32_t* __restrict__ order,
     int32_t* __restrict__ last_iter) {
     using LyT = QpLayout<NQ>;
-    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = LyT::NL,
-                  LC0 = LyT::LC0;
+    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
+                  LC0 = LyT::LC0, KS = LyT::KS;
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS, MRP_MAX = qp_even_c(MR_MAX);
     constexpr int NRC_MAX = NQ + MR_MAX + 1;
     static_assert(MRT < 0 || NX + NRC_MAX <= NL, "one lane per constraint row");
-    static_assert(LC0 + NQ <= NL, "one lane per column of [G | rho | I]");
+    static_assert(KS <= NL, "one lane per column of [G | rho | I]");
     constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
-    constexpr int IMG_MAX = (NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4 + 63) & ~63;
-    constexpr int IMG_PF = IMG_MAX / 64;
+    constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
+    constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
 #ifdef QP_PROFILE
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -479,11 +474,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // call (instances are independent, so the order only changes the makespan, never a result)
     const int b = order ? order[slot] : slot;
     const LyT Ly(MRT >= 0 ? MRT : D->n_rows);
-    const int MR = Ly.MR, MRP = Ly.MRP, NRC = Ly.NRC;
+    const int MR = Ly.MR, MRP = Ly.MRP, NRC = Ly.NRC, NRT = Ly.NRT;
     const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;
     double* const ws = ws_all + (size_t)b * Ly.per_instance(N);
     const double dt = D->dt, cB = 0.5 * dt * dt;
-    const int img_pf = Ly.nIMG >> 6;   // 16-byte loads per lane that cover the image (<= IMG_PF)
+    const int img_n2 = Ly.nIMG >> 1;   // 16-byte pieces of the image
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
     constexpr int O_TD = IMG_MAX, O_GD = O_TD + NZ * NQP, O_D = O_GD + NQ * MRP_MAX, O_E = O_D + NL, O_LAM = O_E + NL,
@@ -535,9 +530,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // lane roles (clamped indices keep every load unconditional)
     const int hl_u = hl < NQ ? hl : NQ - 1;                          // control owned / aliased by this lane
     const int hl_x = hl < NX ? hl : NX - 1;                          // state component
-    const int hl_c = hl >= NX && hl < NX + NRC ? hl - NX : 0;        // general row
-    const int hl_px = hl >= NU && hl < NZ ? hl - NU : 0;             // state component of the lanes NU..NZ-1
-    const bool soft_lane = (hl == rNN);
+    const int hr = hl < NRT ? hl : NRT - 1;                          // constraint row (lanes >= NRT duplicate the last one)
+    const bool row_live = hl < NRT;                                  // ... and stay out of the sums
+    const int hl_c = hr >= NX ? hr - NX : 0;                         // general row
+    const int hz = hl < NZ ? hl : NZ - 1;                            // variable [u; x]
+    const int hl_px = hz >= NU ? hz - NU : 0;                        // state component of the lanes NU..
+    const int hc = hl < KS ? hl : KS - 1;                            // column of [G | rho | . | I]
+    const bool soft_lane = (hr == rNN);
 
     // ---- Cholesky factor in registers (every lane redundantly): strictly-lower entries + inverse diagonal -----------------
     double Lr[NQ][NQ], Linv[NQ];
@@ -615,21 +614,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         {
             dbl2 img[IMG_PF];
             QpRow rs;
-            QpDir rd;
             dbl2 slb;
-            double zc, znc;
+            double zc, znc, czar, cznr;
             auto load_b1 = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
 #pragma unroll
-                for (int j = 0; j < IMG_PF; j++)
-                    if (j < img_pf) img[j] = s2[hl + 32 * j];
-                const double* wr = w + Ly.oLO + hl;
-                rs.lo = wr[0]; rs.hi = wr[NL]; rs.tl = wr[2 * NL]; rs.tu = wr[3 * NL]; rs.ll = wr[4 * NL]; rs.lu = wr[5 * NL];
-                rd.dtl = wr[7 * NL]; rd.dtu = wr[8 * NL]; rd.dll = wr[9 * NL]; rd.dlu = wr[10 * NL];
+                for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
+                const double* wr = w + Ly.oLO + hr;
+                rs.lo = wr[0]; rs.hi = wr[NRT]; rs.tl = wr[2 * NRT]; rs.tu = wr[3 * NRT]; rs.ll = wr[4 * NRT]; rs.lu = wr[5 * NRT];
+                czar = wr[6 * NRT]; cznr = wr[7 * NRT];
                 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                zc = w[Ly.oZ + hl];
-                znc = w[Ly.oZN + hl];
+                zc = w[Ly.oZ + hz];
+                znc = w[Ly.oZN + hz];
             };
             auto stage_b1 = [&](int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
@@ -639,36 +636,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 {
                     dbl2* d2 = reinterpret_cast<dbl2*>(sIMG);
 #pragma unroll
-                    for (int j = 0; j < IMG_PF; j++)
-                        if (j < img_pf) d2[hl + 32 * j] = img[j];
+                    for (int j = 0; j < IMG_PF; j++) d2[min(hl + 32 * j, img_n2 - 1)] = img[j];
                 }
                 const double wsoft = slb.x;
                 const bool bflag = !last && slb.y != 0.0;
                 {
                     const bool soft = soft_lane && wsoft >= 0.0;
+                    // the step of this row, recomputed exactly as F2 did from the values it left behind
+                    double rr_ = 0.0, s1_ = 0.0, s2_ = 0.0;
+                    const QpDir rd = qp_row_dir(rs, soft, wsoft, cznr, sigmu, corr_w, czar, &rr_, &s1_, &s2_);
                     rs.tl += alpha * rd.dtl; rs.ll += alpha * rd.dll;
                     rs.tu += alpha * rd.dtu; rs.lu += alpha * rd.dlu;
-                    double* wr = w + Ly.oLO + hl;
-                    wr[2 * NL] = rs.tl; wr[3 * NL] = rs.tu; wr[4 * NL] = rs.ll; wr[5 * NL] = rs.lu;
+                    double* wr = w + Ly.oLO + hr;
+                    wr[2 * NRT] = rs.tl; wr[3 * NRT] = rs.tu; wr[4 * NRT] = rs.ll; wr[5 * NRT] = rs.lu;
                     double Dr;
-                    sE[hl] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
-                    sD[hl] = Dr;
-                    mu_new += qp_row_comp(rs, soft, wsoft);
+                    sE[hr] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
+                    sD[hr] = Dr;
+                    mu_new += row_live ? qp_row_comp(rs, soft, wsoft) : 0.0;
                 }
                 zc += alpha * (znc - zc);
-                w[Ly.oZ + hl] = zc;
+                w[Ly.oZ + hz] = zc;
                 lds_fence();
                 QPT(0);
                 load_b1(k > 0 ? k - 1 : 0);
                 // -- P b, and the rows scaled by their barrier weights
                 {
                     double a = 0.0;
-                    if (bflag && hl < NX) {
+                    if (bflag) {
 #pragma unroll
-                        for (int jx = 0; jx < NX; jx++) a = fma(Pc[hl * NX + jx], sB[jx], a);
+                        for (int jx = 0; jx < NX; jx++) a = fma(Pc[hl_x * NX + jx], sB[jx], a);
                     }
-                    if (hl < NX) sPB[hl] = a;
-                    w[Ly.oPB + hl] = a;
+                    sPB[hl_x] = a;
+                    w[Ly.oPB + hl_x] = a;
                 }
                 for (int el = hl; el < NZ * NQP; el += 32) {
                     const int r = el % NQP;
@@ -747,12 +746,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 if (!last) {
                     if (!chol_from_lds(sLam)) broke = true;
                     // one column per lane: [W | w] = L^-1 [G | rho], [K | k] = L^-T [W | w]; lanes LC0.. do the same to the
-                    // unit vectors, which leaves L^-1 next to W; every lane stores its column (row stride NL)
+                    // unit vectors, which leaves L^-1 next to W; every lane stores its column
                     {
                         double col[NQ];
-                        const int cg = hl <= NX ? hl : NX;
+                        const int cg = hc <= NX ? hc : NX;
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) col[i] = hl <= NX ? sG[i * WS2 + cg] : (i == hl - LC0 ? 1.0 : 0.0);
+                        for (int i = 0; i < NQ; i++) col[i] = hc <= NX ? sG[i * WS2 + cg] : (i == hc - LC0 ? 1.0 : 0.0);
 #pragma unroll
                         for (int i = 0; i < NQ; i++) {
                             double v = col[i];
@@ -760,12 +759,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             for (int t = 0; t < i; t++) v = fma(-Lr[i][t], col[t], v);
                             col[i] = v * Linv[i];
                         }
-                        if (hl <= NX) {
+                        if (hc <= NX) {
 #pragma unroll
-                            for (int i = 0; i < NQ; i++) sWT[hl * NQP + i] = col[i];
+                            for (int i = 0; i < NQ; i++) sWT[hc * NQP + i] = col[i];
                         }
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) w[Ly.oW + i * NL + hl] = col[i];
+                        for (int i = 0; i < NQ; i++) w[Ly.oW + i * KS + hc] = col[i];
 #pragma unroll
                         for (int i = NQ - 1; i >= 0; i--) {
                             double v = col[i];
@@ -774,7 +773,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             col[i] = v * Linv[i];
                         }
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) w[Ly.oK + i * NL + hl] = col[i];
+                        for (int i = 0; i < NQ; i++) w[Ly.oK + i * KS + hc] = col[i];
                     }
                     lds_fence();
                     QPT(3);
@@ -837,7 +836,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             double bi, czar = 0.0;
             double *xb = sIMG + O_XB, *xn = sIMG + O_XB + NX;
             auto load_k = [&](int k) {
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(ws + (size_t)k * Ly.stride + Ly.oK + hl_u * NL);
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(ws + (size_t)k * Ly.stride + Ly.oK + hl_u * KS);
 #pragma unroll
                 for (int j = 0; j < WS2 / 2; j++) Kr[j] = s2[j];
             };
@@ -848,9 +847,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             };
             auto load_r = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
-                const double* wr = w + Ly.oLO + hl;
-                rs.lo = wr[0]; rs.hi = wr[NL]; rs.tl = wr[2 * NL]; rs.tu = wr[3 * NL]; rs.ll = wr[4 * NL]; rs.lu = wr[5 * NL];
-                if (CORR) czar = wr[6 * NL];
+                const double* wr = w + Ly.oLO + hr;
+                rs.lo = wr[0]; rs.hi = wr[NRT]; rs.tl = wr[2 * NRT]; rs.tu = wr[3 * NRT]; rs.ll = wr[4 * NRT]; rs.lu = wr[5 * NRT];
+                if (CORR) czar = wr[6 * NRT];
                 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
             };
             if (hl < NX) xb[hl] = dx0_reg;
@@ -892,19 +891,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int c = 0; c < NU; c++) a = fma(cr[c], sZU[c], a);
 #pragma unroll
                     for (int c = 0; c < NX; c++) a = fma(cr[NU + c], xb[c], a);
-                    const double cz = hl < NX ? xb[hl_x] : a;
+                    const double cz = hr < NX ? xb[hl_x] : a;
                     load_c(kn);
                     const double wsoft = slb.x;
                     const bool soft = soft_lane && wsoft >= 0.0;
-                    double* wr = w + Ly.oLO + hl;
+                    double* wr = w + Ly.oLO + hr;
+                    double s1_ = 0.0, s2_ = 0.0;
                     if (!CORR) {
-                        qp_row_dir(rs, soft, wsoft, cz, 0.0, 0.0, 0.0, &rr, &S1, &S2);
-                        wr[6 * NL] = cz;
+                        qp_row_dir(rs, soft, wsoft, cz, 0.0, 0.0, 0.0, &rr, &s1_, &s2_);
+                        wr[6 * NRT] = cz;
                     } else {
-                        const QpDir d = qp_row_dir(rs, soft, wsoft, cz, sigmu, corr_w, czar, &rr, &S1, &S2);
-                        wr[7 * NL] = d.dtl; wr[8 * NL] = d.dtu; wr[9 * NL] = d.dll; wr[10 * NL] = d.dlu;
-                        w[Ly.oZN + hl] = hl < NU ? sZU[hl_u] : xb[hl_px];
+                        qp_row_dir(rs, soft, wsoft, cz, sigmu, corr_w, czar, &rr, &s1_, &s2_);
+                        wr[7 * NRT] = cz;
+                        w[Ly.oZN + hz] = hz < NU ? sZU[hl_u] : xb[hl_px];
                     }
+                    S1 += row_live ? s1_ : 0.0;
+                    S2 += row_live ? s2_ : 0.0;
                     load_r(kn);
                 }
                 lds_fence();
@@ -936,26 +938,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             double Cc[NRC_MAX], LIr[NQP], LIc[NQ], Wc[NQ];
             auto load_r = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
-                const double* wr = w + Ly.oLO + hl;
-                rs.lo = wr[0]; rs.hi = wr[NL]; rs.tl = wr[2 * NL]; rs.tu = wr[3 * NL]; rs.ll = wr[4 * NL]; rs.lu = wr[5 * NL];
-                czar = wr[6 * NL];
+                const double* wr = w + Ly.oLO + hr;
+                rs.lo = wr[0]; rs.hi = wr[NRT]; rs.tl = wr[2 * NRT]; rs.tu = wr[3 * NRT]; rs.ll = wr[4 * NRT]; rs.lu = wr[5 * NRT];
+                czar = wr[6 * NRT];
                 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                pbr = w[Ly.oPB + hl];
+                pbr = w[Ly.oPB + hl_x];
             };
             auto load_g = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
 #pragma unroll
                 for (int r = 0; r < NRC_MAX; r++)
-                    if (r < NRC) Cc[r] = w[Ly.oC + r * NZP + hl];   // (lanes >= NZ read into the next block: unused)
-                gzr = w[Ly.oIMG + Ly.iGZ + (hl < NZ ? hl : 0)];
+                    if (r < NRC) Cc[r] = w[Ly.oC + r * NZP + hz];
+                gzr = w[Ly.oIMG + Ly.iGZ + hz];
             };
             auto load_f = [&](int k) {  // factors of stage k < N: row and column of L^-1, column of W
                 const double* w = ws + (size_t)k * Ly.stride;
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oW + hl_u * NL + LC0);
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oW + hl_u * KS + LC0);
 #pragma unroll
                 for (int j = 0; j < NQP / 2; j++) { const dbl2 v = s2[j]; LIr[2 * j] = v.x; LIr[2 * j + 1] = v.y; }
 #pragma unroll
-                for (int t = 0; t < NQ; t++) { LIc[t] = w[Ly.oW + t * NL + LC0 + hl_u]; Wc[t] = w[Ly.oW + t * NL + hl_px]; }
+                for (int t = 0; t < NQ; t++) { LIc[t] = w[Ly.oW + t * KS + LC0 + hl_u]; Wc[t] = w[Ly.oW + t * KS + hl_px]; }
             };
             auto stage_b2 = [&](int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
@@ -966,9 +968,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     const double wsoft = slb.x;
                     const bool soft = soft_lane && wsoft >= 0.0;
                     double Dr;
-                    sE[hl] = qp_row_coeff(rs, soft, wsoft, sigmu, corr_w, czar, &Dr);
+                    sE[hr] = qp_row_coeff(rs, soft, wsoft, sigmu, corr_w, czar, &Dr);
                 }
-                if (!last && hl < NX) sQ[hl] = pvc[hl] + pbr;   // p_{k+1} + P b
+                if (!last) sQ[hl_x] = pvc[hl_x] + pbr;          // p_{k+1} + P b
                 load_r(kp);
                 lds_fence();
                 QPT(8);
@@ -978,9 +980,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                     for (int r = 0; r < NRC_MAX; r++)
                         if (r < NRC) gh = fma(Cc[r], sE[NX + r], gh);
-                    if (hl >= NU) gh += sE[hl - NU];
+                    if (hz >= NU) gh += sE[hz - NU];
                     if (last) {
-                        if (hl >= NU && hl < NZ) pvn[hl - NU] = gh;
+                        if (hz >= NU) pvn[hz - NU] = gh;
                     } else if (hl < NU) {
                         sRho[hl] = gh + cB * sQ[hl] + dt * sQ[NQ + hl];
                     } else {
@@ -1005,10 +1007,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         kv = fma(LIc[j], wj, kv);
                         pv = fma(Wc[j], wj, pv);
                     }
-                    double* dst = hl < NQ ? w + Ly.oK + hl * NL + NX : w + Ly.oDUM + hl;
-                    *dst = kv;
-                    if (k > 0 && hl >= NU && hl < NZ) {
-                        const int i = hl - NU;
+                    w[Ly.oK + hl_u * KS + NX] = kv;
+                    if (k > 0 && hz >= NU) {
+                        const int i = hz - NU;
                         pvn[i] = ghx + (i < NQ ? sQ[i] : dt * sQ[i - NQ] + sQ[i]) - pv;
                     }
                     load_f(kp);
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll 4
     for (int k = 0; k <= N; k++) {
         const double* w = ws + (size_t)k * Ly.stride;
-        const double z = w[Ly.oZ + hl], zn = w[Ly.oZN + hl];
+        const double z = w[Ly.oZ + hz], zn = w[Ly.oZN + hz];
         const int ku = k < N ? k : N - 1;
         const double base = hl < NU ? ub0[(size_t)ku * NU + hl_u] : xb0[(size_t)k * NX + hl_px];
         const double v = base + z + a_fin * (zn - z);
