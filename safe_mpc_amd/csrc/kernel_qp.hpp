@@ -57,9 +57,9 @@ template <int NQ> struct QpLayout {
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
-    int oC, oIMG, oK, oW, oSL;                                  // 16-byte aligned blocks
+    int oC, oIMG, oW, oSL;                                      // 16-byte aligned blocks
     int oLO, oHI, oTL, oTU, oLL, oLU, oCZA, oCZN;               // one entry per row, NRT each, contiguous
-    int oZ, oZN, oPB, oPART;
+    int oZ, oZN, oGH0, oA1, oA2, oPB, oPART;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
         MR = n_rows;
@@ -78,8 +78,7 @@ template <int NQ> struct QpLayout {
         int o = 0;
         oC = o; o += NRC * NZP;            // general rows, row-major (F: rows, B2: columns)
         oIMG = o; o += nIMG;
-        oK = o; o += NQ * KS;              // gain rows [K_i | k_i | ...]                = L^-T L^-1 [G | rho | I]
-        oW = o; o += NQ * KS;              // half-way rows [W_i | w_i | . | L^-1_i | .] = L^-1 [G | rho | I]
+        oW = o; o += NQ * KS;              // factor rows [W_i | w_i | . | L^-1_i | .] = L^-1 [G | rho | I]
         oSL = o; o += 2;                   // [soft weight, b != 0]
         oLO = o; o += NRT;
         oHI = o; o += NRT;
@@ -91,6 +90,9 @@ template <int NQ> struct QpLayout {
         oCZN = o; o += NRT;                // c . z+    of every row (F2 -> B1)
         oZ = o; o += NZ;
         oZN = o; o += NZ;
+        oGH0 = o; o += NZ;                 // predictor gradient g + C^T e0 (B1 -> B2)
+        oA1 = o; o += NZ;                  // C^T e1, C^T e2: the corrector gradient is gh0 + sigma mu a1 + cw a2 (F1 -> B2)
+        oA2 = o; o += NZ;
         oPB = o; o += NX;                  // P b
         oPART = o; o += 4;                 // setup partials [R0, sum lambda t, count]
         stride = qp_even_c(o);
@@ -146,9 +148,12 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 struct QpRow { double lo, hi, tl, tu, ll, lu; };
 struct QpDir { double dtl, dll, dtu, dlu; };
 
-// one side: gap = distance of the trial point to the bound, gap_a the same for z_aff; returns the largest -d/v in *rr
-__device__ __forceinline__ void qp_side_dir(bool has, double gap, double gap_a, double t, double l, double sigmu, double cw,
-                                            double* dt_o, double* dl_o, double* rr, double* S1, double* S2) {
+// one side: gap = distance of the trial point to the bound, gap_a the same for z_aff; returns the largest -d/v in *rr.
+// WANT_E: also the side's share of e1, e2, where the gradient coefficient of the row is e0 + sigma mu e1 + cw e2
+template <bool WANT_E>
+__device__ __forceinline__ void qp_side_dir(bool has, double sgn, double gap, double gap_a, double t, double l, double sigmu,
+                                            double cw, double* dt_o, double* dl_o, double* rr, double* S1, double* S2,
+                                            double* e1, double* e2) {
     const double ls = has ? l : 1.0;
     const double r = fast_rcp(t * ls);      // one reciprocal serves 1/t and 1/lambda
     const double it = ls * r, il = t * r;
@@ -163,15 +168,22 @@ __device__ __forceinline__ void qp_side_dir(bool has, double gap, double gap_a, 
     *rr = fmax(*rr, fmax(-dt_ * it, -dl_ * il));
     *S1 += l * dt_ + t * dl_;
     *S2 += dl_ * dt_;
+    if (WANT_E) {
+        const double m = has ? sgn * it : 0.0;
+        *e1 += m;
+        *e2 -= dta * dla * m;
+    }
 }
 // directions of one row for the trial value czn = c.z+, ratio-test term and the terms of sum(lambda t)(alpha)
+template <bool WANT_E>
 __device__ __forceinline__ QpDir qp_row_dir(const QpRow& s, bool soft, double wsoft, double czn, double sigmu, double cw,
-                                            double cza, double* rr, double* S1, double* S2) {
+                                            double cza, double* rr, double* S1, double* S2, double* e1, double* e2) {
     QpDir o;
     const bool hasl = s.lo > -QP_ABSENT, hasu = s.hi < QP_ABSENT;
     const double lo = hasl ? s.lo : 0.0, hi = hasu ? s.hi : 0.0;
-    qp_side_dir(hasl && !soft, czn - lo, cza - lo, s.tl, s.ll, sigmu, cw, &o.dtl, &o.dll, rr, S1, S2);
-    qp_side_dir(hasu, hi - czn, hi - cza, s.tu, s.lu, sigmu, cw, &o.dtu, &o.dlu, rr, S1, S2);
+    if (WANT_E) { *e1 = 0.0; *e2 = 0.0; }
+    qp_side_dir<WANT_E>(hasl && !soft, -1.0, czn - lo, cza - lo, s.tl, s.ll, sigmu, cw, &o.dtl, &o.dll, rr, S1, S2, e1, e2);
+    qp_side_dir<WANT_E>(hasu, 1.0, hi - czn, hi - cza, s.tu, s.lu, sigmu, cw, &o.dtu, &o.dlu, rr, S1, S2, e1, e2);
     if (soft) {
         const double tl = s.tl, ll = s.ll, sl = s.tu;
         const double nu = wsoft - ll;
@@ -191,6 +203,10 @@ __device__ __forceinline__ QpDir qp_row_dir(const QpRow& s, bool soft, double ws
         *rr = fmax(*rr, fmax(fmax(-dtl / tl, -dl * ill), fmax(-dsl / sl, dl * inu)));
         *S1 += ll * dtl + tl * dl + nu * dsl - sl * dl;
         *S2 += dl * dtl - dl * dsl;
+        if (WANT_E) {
+            *e1 = deff * (inu - ill);
+            *e2 = deff * dla * (dsa * inu + dta * ill);
+        }
     }
     return o;
 }
@@ -504,7 +520,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sWT = sIMG + O_WT;
     double* const sHXX = sIMG + O_HXX;
     double* const sPB = sIMG + O_PB;
-    double* const sQ = sIMG + O_Q;
     double* const sZU = sIMG + O_ZU;
     double* const sRho = sIMG + O_RHO;
     double* const sWv = sIMG + O_WV;
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     const bool soft = soft_lane && wsoft >= 0.0;
                     // the step of this row, recomputed exactly as F2 did from the values it left behind
                     double rr_ = 0.0, s1_ = 0.0, s2_ = 0.0;
-                    const QpDir rd = qp_row_dir(rs, soft, wsoft, cznr, sigmu, corr_w, czar, &rr_, &s1_, &s2_);
+                    const QpDir rd = qp_row_dir<false>(rs, soft, wsoft, cznr, sigmu, corr_w, czar, &rr_, &s1_, &s2_, nullptr, nullptr);
                     rs.tl += alpha * rd.dtl; rs.ll += alpha * rd.dll;
                     rs.tu += alpha * rd.dtu; rs.lu += alpha * rd.dlu;
                     double* wr = w + Ly.oLO + hr;
@@ -721,19 +736,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 }
                 // -- gradient: g + C^T e; lanes NU.. keep the x part in a register for the costate update
                 double ghx = 0.0;
-                if (hl < NZ) {
-                    double gh = sGZ[hl];
+                {
+                    double gh = sGZ[hz];
 #pragma unroll
-                    for (int r = 0; r < NQ; r++) gh = fma(sTT[hl * NQP + r], sE[rT0 + r], gh);
-                    if (hl >= NU) {
-                        const int ix = hl - NU;
+                    for (int r = 0; r < NQ; r++) gh = fma(sTT[hz * NQP + r], sE[rT0 + r], gh);
+                    if (hz >= NU) {
+                        const int ix = hz - NU;
                         gh += sE[ix];
                         gh = fma(sGN[ix], sE[rNN], gh);
                         if (ix < NQ)
                             for (int r = 0; r < MR; r++) gh = fma(sGT[ix * MRP + r], sE[rC0 + r], gh);
                     }
+                    w[Ly.oGH0 + hz] = gh;   // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one
                     if (last) {
-                        if (hl >= NU) pvn[hl - NU] = gh;
+                        if (hz >= NU) pvn[hz - NU] = gh;
                     } else if (hl < NU) {
                         // rho = gh_u + B^T (p_{k+1} + P b)
                         sG[hl * WS2 + NX] = gh + cB * (pvc[hl] + sPB[hl]) + dt * (pvc[NQ + hl] + sPB[NQ + hl]);
@@ -745,8 +761,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 QPT(2);
                 if (!last) {
                     if (!chol_from_lds(sLam)) broke = true;
-                    // one column per lane: [W | w] = L^-1 [G | rho], [K | k] = L^-T [W | w]; lanes LC0.. do the same to the
-                    // unit vectors, which leaves L^-1 next to W; every lane stores its column
+                    // one column per lane: [W | w] = L^-1 [G | rho]; lanes LC0.. do the same to the unit vectors, which
+                    // leaves L^-1 next to W; every lane stores its column
                     {
                         double col[NQ];
                         const int cg = hc <= NX ? hc : NX;
@@ -765,15 +781,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         }
 #pragma unroll
                         for (int i = 0; i < NQ; i++) w[Ly.oW + i * KS + hc] = col[i];
-#pragma unroll
-                        for (int i = NQ - 1; i >= 0; i--) {
-                            double v = col[i];
-#pragma unroll
-                            for (int t = i + 1; t < NQ; t++) v = fma(-Lr[t][i], col[t], v);
-                            col[i] = v * Linv[i];
-                        }
-#pragma unroll
-                        for (int i = 0; i < NQ; i++) w[Ly.oK + i * KS + hc] = col[i];
                     }
                     lds_fence();
                     QPT(3);
@@ -824,26 +831,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             if (!(mu == mu)) { st_code = 4; break; }
         }
 
-        // ---------------- forward sweeps: roll-out through the stored gains, ratio tests ---------------------------------------
-        // F1 (predictor): c.z_aff of every row is stored for B2 / F2.   F2 (corrector): z+ and the row directions are stored.
+        // ---------------- forward sweeps: roll-out through the stored factors, ratio tests -------------------------------------
+        // F1 (predictor): stores c.z_aff of every row (for F2, B1) and the two vectors a1 = C^T e1, a2 = C^T e2 that make the
+        //                 corrector gradient gh0 + sigma mu a1 + cw a2 -- B2 then never touches the rows or the Jacobian.
+        // F2 (corrector): stores z+ and c.z+ of every row.
         // Returns the largest ratio -d/v over all slacks and multipliers (its reciprocal is the step to the boundary).
         auto sweep_f = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
             double rr = 0.0, S1 = 0.0, S2 = 0.0;
-            dbl2 Kr[WS2 / 2], Cr[NZP / 2];
+            dbl2 Wr[WS2 / 2], Cr[NZP / 2];
+            double LIc[NQ], Cc[CORR ? 1 : NRC_MAX];
             QpRow rs;
             dbl2 slb;
             double bi, czar = 0.0;
             double *xb = sIMG + O_XB, *xn = sIMG + O_XB + NX;
-            auto load_k = [&](int k) {
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(ws + (size_t)k * Ly.stride + Ly.oK + hl_u * KS);
+            auto load_k = [&](int k) {   // factor row i = [W_i | w_i] and column i of L^-1
+                const double* wk = ws + (size_t)k * Ly.stride + Ly.oW;
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(wk + hl_u * KS);
 #pragma unroll
-                for (int j = 0; j < WS2 / 2; j++) Kr[j] = s2[j];
+                for (int j = 0; j < WS2 / 2; j++) Wr[j] = s2[j];
+#pragma unroll
+                for (int j = 0; j < NQ; j++) LIc[j] = wk[j * KS + LC0 + hl_u];
             };
             auto load_c = [&](int k) {
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(ws + (size_t)k * Ly.stride + Ly.oC + hl_c * NZP);
 #pragma unroll
                 for (int j = 0; j < NZP / 2; j++) Cr[j] = s2[j];
+            };
+            auto load_cc = [&](int k) {  // F1: this lane's column of the general rows
+                if (!CORR) {
+                    const double* w = ws + (size_t)k * Ly.stride;
+#pragma unroll
+                    for (int r = 0; r < NRC_MAX; r++)
+                        if (r < NRC) Cc[r] = w[Ly.oC + r * NZP + hz];
+                }
             };
             auto load_r = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
@@ -857,20 +878,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             bi = ws[Ly.oIMG + Ly.iB + hl_x];
             load_c(0);
             load_r(0);
+            load_cc(0);
             lds_fence();
 #pragma unroll 1
             for (int k = 0; k <= N; k++) {
                 if (CORR) asm volatile("; QPMARK F2_BEGIN"); else asm volatile("; QPMARK F1_BEGIN");
                 const bool last = (k == N);
                 const int kn = k < N ? k + 1 : N;          // the end stage re-loads itself: every load stays unconditional
-                const int kk = kn < N ? kn : N - 1;        // (there are no gains at the end stage)
+                const int kk = kn < N ? kn : N - 1;        // (there are no factors at the end stage)
                 double* w = ws + (size_t)k * Ly.stride;
-                // u_i = -(K_i x + k_i): one lane per control, x broadcast from LDS
+                // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
-                    const double* kr = reinterpret_cast<const double*>(Kr);
-                    double a = kr[NX];
+                    const double* wr_ = reinterpret_cast<const double*>(Wr);
+                    double a = wr_[NX];
 #pragma unroll
-                    for (int j = 0; j < NX; j++) a = fma(kr[j], xb[j], a);
+                    for (int j = 0; j < NX; j++) a = fma(wr_[j], xb[j], a);
+                    if (hl < NQ) sRho[hl] = a;
+                }
+                lds_fence();
+                {
+                    double a = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) a = fma(LIc[j], sRho[j], a);
                     if (hl < NQ) sZU[hl] = last ? 0.0 : -a;
                 }
                 load_k(kk);
@@ -898,10 +927,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     double* wr = w + Ly.oLO + hr;
                     double s1_ = 0.0, s2_ = 0.0;
                     if (!CORR) {
-                        qp_row_dir(rs, soft, wsoft, cz, 0.0, 0.0, 0.0, &rr, &s1_, &s2_);
+                        double e1, e2;
+                        qp_row_dir<true>(rs, soft, wsoft, cz, 0.0, 0.0, cz, &rr, &s1_, &s2_, &e1, &e2);
                         wr[6 * NRT] = cz;
+                        sD[hr] = e1;     // (B1's D / E arrays are free during the forward sweeps)
+                        sE[hr] = e2;
                     } else {
-                        qp_row_dir(rs, soft, wsoft, cz, sigmu, corr_w, czar, &rr, &s1_, &s2_);
+                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, czar, &rr, &s1_, &s2_, nullptr, nullptr);
                         wr[7 * NRT] = cz;
                         w[Ly.oZN + hz] = hz < NU ? sZU[hl_u] : xb[hl_px];
                     }
@@ -910,6 +942,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     load_r(kn);
                 }
                 lds_fence();
+                if (!CORR) {
+                    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                    for (int r = 0; r < NRC_MAX; r++)
+                        if (r < NRC) { a1 = fma(Cc[r], sD[NX + r], a1); a2 = fma(Cc[r], sE[NX + r], a2); }
+                    if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
+                    w[Ly.oA1 + hz] = a1;
+                    w[Ly.oA2 + hz] = a2;
+                    load_cc(kn);   // (the next stage rewrites e1 / e2 only after its two chain fences)
+                }
                 { double* t = xb; xb = xn; xn = t; }
                 QPT(CORR ? 11 : 7);
                 if (CORR) asm volatile("; QPMARK F2_END"); else asm volatile("; QPMARK F1_END");
@@ -930,87 +972,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         // safeguard against Mehrotra cycling (see oracle): damp the second-order term when the affine step is blocked early
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
 
-        // ---------------- sweep B2: corrector gradient and costate recursion with the stored gains --------------------------
+        // ---------------- sweep B2: costate recursion of the corrector with the stored factors -------------------------------
         {
-            QpRow rs;
-            dbl2 slb;
-            double czar, pbr, gzr;
-            double Cc[NRC_MAX], LIr[NQP], LIc[NQ], Wc[NQ];
-            auto load_r = [&](int k) {
-                const double* w = ws + (size_t)k * Ly.stride;
-                const double* wr = w + Ly.oLO + hr;
-                rs.lo = wr[0]; rs.hi = wr[NRT]; rs.tl = wr[2 * NRT]; rs.tu = wr[3 * NRT]; rs.ll = wr[4 * NRT]; rs.lu = wr[5 * NRT];
-                czar = wr[6 * NRT];
-                slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                pbr = w[Ly.oPB + hl_x];
-            };
+            double gh0r, a1r, a2r, pb1, pb2;
+            double LIr[NQP], Wc[NQ];
+            // the two entries of P b this lane needs: controls (i, NQ+i), states (ix, ix-NQ)
+            const int ip1 = hl < NU ? hl : hl_px;
+            const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
             auto load_g = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
-#pragma unroll
-                for (int r = 0; r < NRC_MAX; r++)
-                    if (r < NRC) Cc[r] = w[Ly.oC + r * NZP + hz];
-                gzr = w[Ly.oIMG + Ly.iGZ + hz];
+                gh0r = w[Ly.oGH0 + hz];
+                a1r = w[Ly.oA1 + hz];
+                a2r = w[Ly.oA2 + hz];
+                pb1 = w[Ly.oPB + ip1];
+                pb2 = w[Ly.oPB + ip2];
             };
-            auto load_f = [&](int k) {  // factors of stage k < N: row and column of L^-1, column of W
+            auto load_f = [&](int k) {  // factors of stage k < N: row of L^-1, column of W
                 const double* w = ws + (size_t)k * Ly.stride;
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oW + hl_u * KS + LC0);
 #pragma unroll
                 for (int j = 0; j < NQP / 2; j++) { const dbl2 v = s2[j]; LIr[2 * j] = v.x; LIr[2 * j + 1] = v.y; }
 #pragma unroll
-                for (int t = 0; t < NQ; t++) { LIc[t] = w[Ly.oW + t * KS + LC0 + hl_u]; Wc[t] = w[Ly.oW + t * KS + hl_px]; }
+                for (int t = 0; t < NQ; t++) Wc[t] = w[Ly.oW + t * KS + hl_px];
             };
             auto stage_b2 = [&](int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
                 asm volatile("; QPMARK B2_BEGIN");
                 double* w = ws + (size_t)k * Ly.stride;
                 const int kp = k > 0 ? k - 1 : 0;
-                {
-                    const double wsoft = slb.x;
-                    const bool soft = soft_lane && wsoft >= 0.0;
-                    double Dr;
-                    sE[hr] = qp_row_coeff(rs, soft, wsoft, sigmu, corr_w, czar, &Dr);
-                }
-                if (!last) sQ[hl_x] = pvc[hl_x] + pbr;          // p_{k+1} + P b
-                load_r(kp);
-                lds_fence();
-                QPT(8);
-                double ghx = 0.0;
-                {
-                    double gh = gzr;
-#pragma unroll
-                    for (int r = 0; r < NRC_MAX; r++)
-                        if (r < NRC) gh = fma(Cc[r], sE[NX + r], gh);
-                    if (hz >= NU) gh += sE[hz - NU];
-                    if (last) {
-                        if (hz >= NU) pvn[hz - NU] = gh;
-                    } else if (hl < NU) {
-                        sRho[hl] = gh + cB * sQ[hl] + dt * sQ[NQ + hl];
-                    } else {
-                        ghx = gh;
-                    }
-                }
-                load_g(kp);
-                lds_fence();
-                if (!last) {
-                    // wv = L^-1 rho ; k = L^-T wv ; p_k = gh_x + A^T (p_{k+1} + P b) - W^T wv
+                const double gh = gh0r + sigmu * a1r + corr_w * a2r;
+                if (last) {
+                    if (hz >= NU) pvn[hz - NU] = gh;
+                    load_g(kp);
+                } else {
+                    // rho = gh_u + B^T q,  q = p_{k+1} + P b ;  wv = L^-1 rho ;  p_k = gh_x + A^T q - W^T wv
+                    const double q1 = pvc[ip1] + pb1, q2 = pvc[ip2] + pb2;
+                    if (hl < NU) sRho[hl] = gh + cB * q1 + dt * q2;
+                    load_g(kp);
+                    lds_fence();
+                    QPT(8);
                     {
                         double v = 0.0;
 #pragma unroll
                         for (int j = 0; j < NQ; j++) v = fma(LIr[j], sRho[j], v);
                         if (hl < NQ) sWv[hl] = v;
+                        w[Ly.oW + hl_u * KS + NX] = v;   // the corrector's w (F2 reads it with the row)
                     }
                     lds_fence();
-                    double kv = 0.0, pv = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NQ; j++) {
-                        const double wj = sWv[j];
-                        kv = fma(LIc[j], wj, kv);
-                        pv = fma(Wc[j], wj, pv);
-                    }
-                    w[Ly.oK + hl_u * KS + NX] = kv;
                     if (k > 0 && hz >= NU) {
-                        const int i = hz - NU;
-                        pvn[i] = ghx + (i < NQ ? sQ[i] : dt * sQ[i - NQ] + sQ[i]) - pv;
+                        double v = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
+#pragma unroll
+                        for (int t = 0; t < NQ; t++) v = fma(-Wc[t], sWv[t], v);
+                        pvn[hl_px] = v;
                     }
                     load_f(kp);
                 }
@@ -1019,7 +1032,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 QPT(9);
                 asm volatile("; QPMARK B2_END");
             };
-            load_r(N);
             load_g(N);
             load_f(N > 0 ? N - 1 : 0);
             stage_b2(N, std::true_type{});
