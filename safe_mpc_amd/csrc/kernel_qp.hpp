@@ -52,13 +52,13 @@ constexpr int qp_even_c(int n) { return (n + 1) & ~1; }
 template <int NQ> struct QpLayout {
     static constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ;
     static constexpr int NZP = qp_even_c(NZ), NQP = qp_even_c(NQ), WS2 = qp_even_c(NX + 1);
-    static constexpr int LC0 = WS2;                    // first column of L^-1 inside the rows of W
-    static constexpr int KS = qp_even_c(LC0 + NQ);     // row stride of the gain blocks = lanes that own a column
+    static constexpr int LC0 = WS2;                    // factor rows: first column of L^-1
+    static constexpr int KS = qp_even_c(LC0 + NQ);     // row stride of the factor block = lanes that own a column
+    static constexpr int RW = 8;                       // doubles per constraint-row record
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
-    int oC, oIMG, oW, oSL;                                      // 16-byte aligned blocks
-    int oLO, oHI, oTL, oTU, oLL, oLU, oCZA, oCZN;               // one entry per row, NRT each, contiguous
+    int oC, oIMG, oW, oSL, oROW;                                // 16-byte aligned blocks
     int oZ, oZN, oGH0, oA1, oA2, oPB, oPART;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
@@ -76,19 +76,12 @@ template <int NQ> struct QpLayout {
         iSC = i; i += 4;                   // [Huu diagonal, LM on the v diagonal, soft weight, b != 0]
         nIMG = i;                          // (even)
         int o = 0;
-        oC = o; o += NRC * NZP;            // general rows, row-major (F: rows, B2: columns)
+        oC = o; o += NRC * NZP;            // general rows, row-major (staged through LDS by the forward sweeps)
         oIMG = o; o += nIMG;
-        oW = o; o += NQ * KS;              // factor rows [W_i | w_i | . | L^-1_i | .] = L^-1 [G | rho | I]
+        oW = o; o += NQ * KS;              // factor rows [W_i | w_i | . | row i of L^-1]
         oSL = o; o += 2;                   // [soft weight, b != 0]
-        oLO = o; o += NRT;
-        oHI = o; o += NRT;
-        oTL = o; o += NRT;
-        oTU = o; o += NRT;                 // (the soft row has no upper side: its slack lives here)
-        oLL = o; o += NRT;
-        oLU = o; o += NRT;
-        oCZA = o; o += NRT;                // c . z_aff of every row (F1 -> B2, F2, B1)
-        oCZN = o; o += NRT;                // c . z+    of every row (F2 -> B1)
-        oZ = o; o += NZ;
+        oROW = o; o += NRT * RW;           // per row [lo, hi | t_l, t_u | lambda_l, lambda_u | c.z_aff, c.z+]
+        oZ = o; o += NZ;                   //   (the soft row has no upper side: its slack lives in t_u)
         oZN = o; o += NZ;
         oGH0 = o; o += NZ;                 // predictor gradient g + C^T e0 (B1 -> B2)
         oA1 = o; o += NZ;                  // C^T e1, C^T e2: the corrector gradient is gh0 + sigma mu a1 + cw a2 (F1 -> B2)
@@ -373,7 +366,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
 
     // ---- static blocks out ---------------------------------------------------------------------------------------------
     for (int el = hl; el < NRC * NZP; el += 32) w[Ly.oC + el] = sC[el];
-    if (hl < NRT) { w[Ly.oLO + hl] = sLO[hl]; w[Ly.oHI + hl] = sHI[hl]; }
+    if (hl < NRT) { w[Ly.oROW + hl * LyT::RW + 0] = sLO[hl]; w[Ly.oROW + hl * LyT::RW + 1] = sHI[hl]; }
     double* img = w + Ly.oIMG;
     for (int el = hl; el < NZ * NQP; el += 32) {
         const int c = el / NQP, r = el - c * NQP;
@@ -430,9 +423,8 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
             }
         }
         if (r < NRT) {
-            w[Ly.oTL + r] = tl; w[Ly.oLL + r] = ll; w[Ly.oTU + r] = tu; w[Ly.oLU + r] = lu;
-            w[Ly.oCZA + r] = 0.0;
-            w[Ly.oCZN + r] = 0.0;
+            double* rp = w + Ly.oROW + r * LyT::RW;
+            rp[2] = tl; rp[3] = tu; rp[4] = ll; rp[5] = lu; rp[6] = 0.0; rp[7] = 0.0;
         }
         sE[r] = -(ll - lu);
     }
@@ -459,6 +451,9 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
 #ifndef QP_WAVES_PER_EU
 #define QP_WAVES_PER_EU 2
 #endif
+#ifndef QP_F_DEPTH
+#define QP_F_DEPTH 1   // stages of look-ahead of the control-chain loads in the forward sweeps (1 or 2)
+#endif
 
 // =========================================================================================================================
 // k_qp_ipm
@@ -471,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     int32_t* __restrict__ last_iter) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
-                  LC0 = LyT::LC0, KS = LyT::KS;
+                  LC0 = LyT::LC0, KS = LyT::KS, RW = LyT::RW;
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS, MRP_MAX = qp_even_c(MR_MAX);
     constexpr int NRC_MAX = NQ + MR_MAX + 1;
     static_assert(MRT < 0 || NX + NRC_MAX <= NL, "one lane per constraint row");
@@ -479,6 +474,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
     constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
     constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
+    constexpr int F_DEPTH = QP_F_DEPTH;
+    constexpr int CST_MAX = NRC_MAX * NZP, CST_PF = (CST_MAX / 2 + 31) / 32;   // general rows staged by the forward sweeps
+    static_assert(CST_MAX <= 3 * NX * NX, "the staged rows reuse the P / Hxx buffers, idle outside B1");
 #ifdef QP_PROFILE
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -495,6 +493,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const ws = ws_all + (size_t)b * Ly.per_instance(N);
     const double dt = D->dt, cB = 0.5 * dt * dt;
     const int img_n2 = Ly.nIMG >> 1;   // 16-byte pieces of the image
+    const int c_n2 = (Ly.NRC * NZP) >> 1;   // ... and of the general rows
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
     constexpr int O_TD = IMG_MAX, O_GD = O_TD + NZ * NQP, O_D = O_GD + NQ * MRP_MAX, O_E = O_D + NL, O_LAM = O_E + NL,
@@ -519,6 +518,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sG = sIMG + O_G;
     double* const sWT = sIMG + O_WT;
     double* const sHXX = sIMG + O_HXX;
+    double* const sCst = sIMG + O_HXX;   // forward sweeps only
     double* const sPB = sIMG + O_PB;
     double* const sZU = sIMG + O_ZU;
     double* const sRho = sIMG + O_RHO;
@@ -552,6 +552,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const int hl_px = hz >= NU ? hz - NU : 0;                        // state component of the lanes NU..
     const int hc = hl < KS ? hl : KS - 1;                            // column of [G | rho | . | I]
     const bool soft_lane = (hr == rNN);
+
+    // Base of stage k's record.  Opaque to the optimiser on purpose: otherwise loop-invariant code motion precomputes one
+    // 64-bit pointer per (block, lane role) pair -- some forty register pairs that live across the whole kernel and spill.
+    // With the barrier every address is  stage base + small per-lane offset + immediate, formed where it is used.
+    // (The barrier sits on the stage index, not on the pointer: a pointer that went through inline asm loses its
+    // address space and turns every global_load into a flat_load, which also counts in lgkmcnt.)
+    auto stage_ptr = [&](int k) -> double* {
+        asm volatile("" : "+v"(k));
+        return ws + (size_t)k * Ly.stride;
+    };
 
     // ---- Cholesky factor in registers (every lane redundantly): strictly-lower entries + inverse diagonal -----------------
     double Lr[NQ][NQ], Linv[NQ];
@@ -632,13 +642,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             dbl2 slb;
             double zc, znc, czar, cznr;
             auto load_b1 = [&](int k) {
-                const double* w = ws + (size_t)k * Ly.stride;
+                const double* w = stage_ptr(k);
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
 #pragma unroll
                 for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
-                const double* wr = w + Ly.oLO + hr;
-                rs.lo = wr[0]; rs.hi = wr[NRT]; rs.tl = wr[2 * NRT]; rs.tu = wr[3 * NRT]; rs.ll = wr[4 * NRT]; rs.lu = wr[5 * NRT];
-                czar = wr[6 * NRT]; cznr = wr[7 * NRT];
+                const dbl2* rp = reinterpret_cast<const dbl2*>(w + Ly.oROW + hr * RW);
+                const dbl2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+                rs.lo = r0.x; rs.hi = r0.y; rs.tl = r1.x; rs.tu = r1.y; rs.ll = r2.x; rs.lu = r2.y;
+                czar = r3.x; cznr = r3.y;
                 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
                 zc = w[Ly.oZ + hz];
                 znc = w[Ly.oZN + hz];
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             auto stage_b1 = [&](int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
                 asm volatile("; QPMARK B1_BEGIN");
-                double* w = ws + (size_t)k * Ly.stride;
+                double* w = stage_ptr(k);
                 // -- image -> LDS; rows: apply the step, barrier weights, predictor coefficients -- all in the owner's registers
                 {
                     dbl2* d2 = reinterpret_cast<dbl2*>(sIMG);
@@ -662,8 +673,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     const QpDir rd = qp_row_dir<false>(rs, soft, wsoft, cznr, sigmu, corr_w, czar, &rr_, &s1_, &s2_, nullptr, nullptr);
                     rs.tl += alpha * rd.dtl; rs.ll += alpha * rd.dll;
                     rs.tu += alpha * rd.dtu; rs.lu += alpha * rd.dlu;
-                    double* wr = w + Ly.oLO + hr;
-                    wr[2 * NRT] = rs.tl; wr[3 * NRT] = rs.tu; wr[4 * NRT] = rs.ll; wr[5 * NRT] = rs.lu;
+                    dbl2* rp = reinterpret_cast<dbl2*>(w + Ly.oROW + hr * RW);
+                    rp[1] = dbl2{rs.tl, rs.tu};
+                    rp[2] = dbl2{rs.ll, rs.lu};
                     double Dr;
                     sE[hr] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
                     sD[hr] = Dr;
@@ -761,8 +773,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 QPT(2);
                 if (!last) {
                     if (!chol_from_lds(sLam)) broke = true;
-                    // one column per lane: [W | w] = L^-1 [G | rho]; lanes LC0.. do the same to the unit vectors, which
-                    // leaves L^-1 next to W; every lane stores its column
+                    // one column per lane: lanes 0..NX solve L [W | w] = [G | rho], lanes LC0.. solve L y = e_j (the rows of
+                    // the factor block then end with the rows of L^-1); every lane stores its column
                     {
                         double col[NQ];
                         const int cg = hc <= NX ? hc : NX;
@@ -836,73 +848,84 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         //                 corrector gradient gh0 + sigma mu a1 + cw a2 -- B2 then never touches the rows or the Jacobian.
         // F2 (corrector): stores z+ and c.z+ of every row.
         // Returns the largest ratio -d/v over all slacks and multipliers (its reciprocal is the step to the boundary).
+        // The loads of the control chain run TWO stages ahead (two register sets, the loop unrolled by two) -- a forward
+        // stage is a few hundred instructions, shorter than the memory latency under load; rows and Jacobian, needed later
+        // in the stage, one stage ahead.
+        struct FSet {
+            double Wr[NX + 1];  // factor row i: [W_i | w_i]
+            double Lt[NQ];      // column i of L^-1
+            double bi;
+        };
+        struct FRow {
+            dbl2 Cs[CST_PF];    // this lane's 16-byte pieces of the general rows (staged through LDS)
+            dbl2 r0, r1, r2;
+            double cza, wsoft;
+        };
+        // n doubles from a 16-byte aligned source, with 16-byte loads and NO over-read: a register that a pending load
+        // will write but nobody reads is "free" to the allocator, and its reuse forces a vmcnt(0) right there
+        auto load_n = [&](double* dst, const double* src, auto n_tag) {
+            constexpr int n = decltype(n_tag)::value;
+            const dbl2* s2 = reinterpret_cast<const dbl2*>(src);
+#pragma unroll
+            for (int j = 0; j < n / 2; j++) { const dbl2 v = s2[j]; dst[2 * j] = v.x; dst[2 * j + 1] = v.y; }
+            if (n & 1) dst[n - 1] = src[n - 1];
+        };
         auto sweep_f = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
             double rr = 0.0, S1 = 0.0, S2 = 0.0;
-            dbl2 Wr[WS2 / 2], Cr[NZP / 2];
-            double LIc[NQ], Cc[CORR ? 1 : NRC_MAX];
-            QpRow rs;
-            dbl2 slb;
-            double bi, czar = 0.0;
             double *xb = sIMG + O_XB, *xn = sIMG + O_XB + NX;
-            auto load_k = [&](int k) {   // factor row i = [W_i | w_i] and column i of L^-1
-                const double* wk = ws + (size_t)k * Ly.stride + Ly.oW;
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(wk + hl_u * KS);
+            FSet SA, SB;
+            FRow R;
+            auto load_k = [&](FSet& S, int k) {
+                const double* w = stage_ptr(k);
+                load_n(S.Wr, w + Ly.oW + hl_u * KS, std::integral_constant<int, NX + 1>{});
+                const double* wk = w + Ly.oW + LC0 + hl_u;
 #pragma unroll
-                for (int j = 0; j < WS2 / 2; j++) Wr[j] = s2[j];
+                for (int j = 0; j < NQ; j++) S.Lt[j] = wk[j * KS];
+                S.bi = w[Ly.oIMG + Ly.iB + hl_x];
+            };
+            auto load_c = [&](FRow& S, int k) {
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(k) + Ly.oC);
 #pragma unroll
-                for (int j = 0; j < NQ; j++) LIc[j] = wk[j * KS + LC0 + hl_u];
+                for (int j = 0; j < CST_PF; j++) S.Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
             };
-            auto load_c = [&](int k) {
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(ws + (size_t)k * Ly.stride + Ly.oC + hl_c * NZP);
-#pragma unroll
-                for (int j = 0; j < NZP / 2; j++) Cr[j] = s2[j];
+            auto load_r = [&](FRow& S, int k) {
+                const double* w = stage_ptr(k);
+                const dbl2* rp = reinterpret_cast<const dbl2*>(w + Ly.oROW + hr * RW);
+                S.r0 = rp[0]; S.r1 = rp[1]; S.r2 = rp[2];
+                // (a plain load here gets merged into a 16-byte one whose upper half nobody reads: see load_n)
+                if (CORR) S.cza = __builtin_nontemporal_load(w + Ly.oROW + hr * RW + 6);
+                S.wsoft = w[Ly.oSL];
             };
-            auto load_cc = [&](int k) {  // F1: this lane's column of the general rows
-                if (!CORR) {
-                    const double* w = ws + (size_t)k * Ly.stride;
-#pragma unroll
-                    for (int r = 0; r < NRC_MAX; r++)
-                        if (r < NRC) Cc[r] = w[Ly.oC + r * NZP + hz];
-                }
-            };
-            auto load_r = [&](int k) {
-                const double* w = ws + (size_t)k * Ly.stride;
-                const double* wr = w + Ly.oLO + hr;
-                rs.lo = wr[0]; rs.hi = wr[NRT]; rs.tl = wr[2 * NRT]; rs.tu = wr[3 * NRT]; rs.ll = wr[4 * NRT]; rs.lu = wr[5 * NRT];
-                if (CORR) czar = wr[6 * NRT];
-                slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-            };
-            if (hl < NX) xb[hl] = dx0_reg;
-            load_k(0);
-            bi = ws[Ly.oIMG + Ly.iB + hl_x];
-            load_c(0);
-            load_r(0);
-            load_cc(0);
-            lds_fence();
-#pragma unroll 1
-            for (int k = 0; k <= N; k++) {
+            auto stage_f = [&](FSet& S, int k) {
                 if (CORR) asm volatile("; QPMARK F2_BEGIN"); else asm volatile("; QPMARK F1_BEGIN");
                 const bool last = (k == N);
-                const int kn = k < N ? k + 1 : N;          // the end stage re-loads itself: every load stays unconditional
-                const int kk = kn < N ? kn : N - 1;        // (there are no factors at the end stage)
-                double* w = ws + (size_t)k * Ly.stride;
+                const int kn = k < N ? k + 1 : N;          // past the end the loads repeat the end stage: they stay unconditional
+                const int kk = k + F_DEPTH < N ? k + F_DEPTH : N - 1;  // (there are no factors at the end stage)
+                double* w = stage_ptr(k);
+                // general rows -> LDS (rows for the constraint lanes, columns for a1 / a2)
+                {
+                    dbl2* d2 = reinterpret_cast<dbl2*>(sCst);
+#pragma unroll
+                    for (int j = 0; j < CST_PF; j++) d2[min(hl + 32 * j, c_n2 - 1)] = R.Cs[j];
+                }
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
-                    const double* wr_ = reinterpret_cast<const double*>(Wr);
-                    double a = wr_[NX];
+                    double a = S.Wr[NX];
 #pragma unroll
-                    for (int j = 0; j < NX; j++) a = fma(wr_[j], xb[j], a);
+                    for (int j = 0; j < NX; j++) a = fma(S.Wr[j], xb[j], a);
                     if (hl < NQ) sRho[hl] = a;
                 }
+                load_c(R, kn);
                 lds_fence();
                 {
                     double a = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) a = fma(LIc[j], sRho[j], a);
+                    for (int j = 0; j < NQ; j++) a = fma(S.Lt[j], sRho[j], a);
                     if (hl < NQ) sZU[hl] = last ? 0.0 : -a;
                 }
-                load_k(kk);
+                const double bi = S.bi;
+                load_k(S, kk);
                 lds_fence();
                 QPT(CORR ? 10 : 6);
                 // x+ = A x + B u + b
@@ -911,50 +934,71 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     const double u = sZU[i];
                     xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi : xb[hl] + dt * u + bi;
                 }
-                bi = ws[(size_t)kk * Ly.stride + Ly.oIMG + Ly.iB + hl_x];
                 // rows: c.z for the trial point, directions, ratio test
                 {
-                    const double* cr = reinterpret_cast<const double*>(Cr);
+                    const double* cr = sCst + hl_c * NZP;
                     double a = 0.0;
 #pragma unroll
                     for (int c = 0; c < NU; c++) a = fma(cr[c], sZU[c], a);
 #pragma unroll
                     for (int c = 0; c < NX; c++) a = fma(cr[NU + c], xb[c], a);
                     const double cz = hr < NX ? xb[hl_x] : a;
-                    load_c(kn);
-                    const double wsoft = slb.x;
+                    const QpRow rs{R.r0.x, R.r0.y, R.r1.x, R.r1.y, R.r2.x, R.r2.y};
+                    const double wsoft = R.wsoft;
                     const bool soft = soft_lane && wsoft >= 0.0;
-                    double* wr = w + Ly.oLO + hr;
+                    double* rp = w + Ly.oROW + hr * RW;
                     double s1_ = 0.0, s2_ = 0.0;
                     if (!CORR) {
                         double e1, e2;
                         qp_row_dir<true>(rs, soft, wsoft, cz, 0.0, 0.0, cz, &rr, &s1_, &s2_, &e1, &e2);
-                        wr[6 * NRT] = cz;
+                        rp[6] = cz;
                         sD[hr] = e1;     // (B1's D / E arrays are free during the forward sweeps)
                         sE[hr] = e2;
                     } else {
-                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, czar, &rr, &s1_, &s2_, nullptr, nullptr);
-                        wr[7 * NRT] = cz;
+                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, R.cza, &rr, &s1_, &s2_, nullptr, nullptr);
+                        rp[7] = cz;
                         w[Ly.oZN + hz] = hz < NU ? sZU[hl_u] : xb[hl_px];
                     }
                     S1 += row_live ? s1_ : 0.0;
                     S2 += row_live ? s2_ : 0.0;
-                    load_r(kn);
+                    load_r(R, kn);
                 }
                 lds_fence();
                 if (!CORR) {
                     double a1 = 0.0, a2 = 0.0;
 #pragma unroll
                     for (int r = 0; r < NRC_MAX; r++)
-                        if (r < NRC) { a1 = fma(Cc[r], sD[NX + r], a1); a2 = fma(Cc[r], sE[NX + r], a2); }
+                        if (r < NRC) {
+                            const double c = sCst[r * NZP + hz];
+                            a1 = fma(c, sD[NX + r], a1);
+                            a2 = fma(c, sE[NX + r], a2);
+                        }
                     if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
                     w[Ly.oA1 + hz] = a1;
                     w[Ly.oA2 + hz] = a2;
-                    load_cc(kn);   // (the next stage rewrites e1 / e2 only after its two chain fences)
+                    lds_fence();   // (the next stage overwrites the staged rows)
                 }
                 { double* t = xb; xb = xn; xn = t; }
                 QPT(CORR ? 11 : 7);
                 if (CORR) asm volatile("; QPMARK F2_END"); else asm volatile("; QPMARK F1_END");
+            };
+            if (hl < NX) xb[hl] = dx0_reg;
+            load_k(SA, 0);
+            load_c(R, 0);
+            load_r(R, 0);
+            if (F_DEPTH == 2) load_k(SB, N > 1 ? 1 : 0);
+            lds_fence();
+            int k = 0;
+            if (F_DEPTH == 2) {
+#pragma unroll 1
+                for (; k + 1 <= N; k += 2) {
+                    stage_f(SA, k);
+                    stage_f(SB, k + 1);
+                }
+                if (k <= N) stage_f(SA, k);
+            } else {
+#pragma unroll 1
+                for (; k <= N; k++) stage_f(SA, k);
             }
             *rr_out = half_max(rr);
             *S1_out = half_sum(S1);
@@ -973,48 +1017,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
 
         // ---------------- sweep B2: costate recursion of the corrector with the stored factors -------------------------------
+        // ~100 instructions per stage: loads run THREE stages ahead (three register sets, the loop unrolled by three)
         {
-            double gh0r, a1r, a2r, pb1, pb2;
-            double LIr[NQP], Wc[NQ];
+            struct BSet { double gh0, a1, a2, pb1, pb2; double LIr[NQ]; double Wc[NQ]; };
             // the two entries of P b this lane needs: controls (i, NQ+i), states (ix, ix-NQ)
             const int ip1 = hl < NU ? hl : hl_px;
             const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
-            auto load_g = [&](int k) {
-                const double* w = ws + (size_t)k * Ly.stride;
-                gh0r = w[Ly.oGH0 + hz];
-                a1r = w[Ly.oA1 + hz];
-                a2r = w[Ly.oA2 + hz];
-                pb1 = w[Ly.oPB + ip1];
-                pb2 = w[Ly.oPB + ip2];
-            };
-            auto load_f = [&](int k) {  // factors of stage k < N: row of L^-1, column of W
-                const double* w = ws + (size_t)k * Ly.stride;
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oW + hl_u * KS + LC0);
+            auto load_b = [&](BSet& S, int k) {
+                const double* w = stage_ptr(k);
+                S.gh0 = w[Ly.oGH0 + hz];
+                S.a1 = w[Ly.oA1 + hz];
+                S.a2 = w[Ly.oA2 + hz];
+                S.pb1 = w[Ly.oPB + ip1];
+                S.pb2 = w[Ly.oPB + ip2];
+                const int kf = k < N ? k : N - 1;   // (there are no factors at the end stage)
+                const double* wf = stage_ptr(kf) + Ly.oW;
+                load_n(S.LIr, wf + hl_u * KS + LC0, std::integral_constant<int, NQ>{});
 #pragma unroll
-                for (int j = 0; j < NQP / 2; j++) { const dbl2 v = s2[j]; LIr[2 * j] = v.x; LIr[2 * j + 1] = v.y; }
-#pragma unroll
-                for (int t = 0; t < NQ; t++) Wc[t] = w[Ly.oW + t * KS + hl_px];
+                for (int t = 0; t < NQ; t++) S.Wc[t] = wf[t * KS + hl_px];
             };
-            auto stage_b2 = [&](int k, auto last_tag) {
+            auto stage_b2 = [&](BSet& S, int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
                 asm volatile("; QPMARK B2_BEGIN");
-                double* w = ws + (size_t)k * Ly.stride;
-                const int kp = k > 0 ? k - 1 : 0;
-                const double gh = gh0r + sigmu * a1r + corr_w * a2r;
+                double* w = stage_ptr(k);
+                const int kp = k > 3 ? k - 3 : 0;
+                const double gh = S.gh0 + sigmu * S.a1 + corr_w * S.a2;
                 if (last) {
                     if (hz >= NU) pvn[hz - NU] = gh;
-                    load_g(kp);
+                    load_b(S, kp);
                 } else {
                     // rho = gh_u + B^T q,  q = p_{k+1} + P b ;  wv = L^-1 rho ;  p_k = gh_x + A^T q - W^T wv
-                    const double q1 = pvc[ip1] + pb1, q2 = pvc[ip2] + pb2;
+                    const double q1 = pvc[ip1] + S.pb1, q2 = pvc[ip2] + S.pb2;
                     if (hl < NU) sRho[hl] = gh + cB * q1 + dt * q2;
-                    load_g(kp);
                     lds_fence();
                     QPT(8);
                     {
                         double v = 0.0;
 #pragma unroll
-                        for (int j = 0; j < NQ; j++) v = fma(LIr[j], sRho[j], v);
+                        for (int j = 0; j < NQ; j++) v = fma(S.LIr[j], sRho[j], v);
                         if (hl < NQ) sWv[hl] = v;
                         w[Ly.oW + hl_u * KS + NX] = v;   // the corrector's w (F2 reads it with the row)
                     }
@@ -1022,21 +1062,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     if (k > 0 && hz >= NU) {
                         double v = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
 #pragma unroll
-                        for (int t = 0; t < NQ; t++) v = fma(-Wc[t], sWv[t], v);
+                        for (int t = 0; t < NQ; t++) v = fma(-S.Wc[t], sWv[t], v);
                         pvn[hl_px] = v;
                     }
-                    load_f(kp);
+                    load_b(S, kp);
                 }
                 lds_fence();
                 if (last || k > 0) { double* t2 = pvc; pvc = pvn; pvn = t2; }
                 QPT(9);
                 asm volatile("; QPMARK B2_END");
             };
-            load_g(N);
-            load_f(N > 0 ? N - 1 : 0);
-            stage_b2(N, std::true_type{});
+            BSet S0, S1b, S2b;
+            load_b(S0, N);
+            load_b(S1b, N >= 1 ? N - 1 : 0);
+            load_b(S2b, N >= 2 ? N - 2 : 0);
+            stage_b2(S0, N, std::true_type{});
+            int k = N - 1;
 #pragma unroll 1
-            for (int k = N - 1; k >= 0; k--) stage_b2(k, std::false_type{});
+            for (; k - 2 >= 0; k -= 3) {
+                stage_b2(S1b, k, std::false_type{});
+                stage_b2(S2b, k - 1, std::false_type{});
+                stage_b2(S0, k - 2, std::false_type{});
+            }
+            if (k >= 0) stage_b2(S1b, k, std::false_type{});
+            if (k - 1 >= 0) stage_b2(S2b, k - 1, std::false_type{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
