@@ -54,11 +54,10 @@ template <int NQ> struct QpLayout {
     static constexpr int NZP = qp_even_c(NZ), NQP = qp_even_c(NQ), WS2 = qp_even_c(NX + 1);
     static constexpr int LC0 = WS2;                    // factor rows: first column of L^-1
     static constexpr int KS = qp_even_c(LC0 + NQ);     // row stride of the factor block = lanes that own a column
-    static constexpr int RW = 8;                       // doubles per constraint-row record
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
-    int oC, oIMG, oW, oSL, oROW;                                // 16-byte aligned blocks
+    int oC, oIMG, oW, oSL, oR0, oR1, oR2, oR3;                  // 16-byte aligned blocks
     int oZ, oZN, oGH0, oA1, oA2, oPB, oPART;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
@@ -80,8 +79,11 @@ template <int NQ> struct QpLayout {
         oIMG = o; o += nIMG;
         oW = o; o += NQ * KS;              // factor rows [W_i | w_i | . | row i of L^-1]
         oSL = o; o += 2;                   // [soft weight, b != 0]
-        oROW = o; o += NRT * RW;           // per row [lo, hi | t_l, t_u | lambda_l, lambda_u | c.z_aff, c.z+]
-        oZ = o; o += NZ;                   //   (the soft row has no upper side: its slack lives in t_u)
+        oR0 = o; o += NRT * 2;             // per row, as arrays of pairs: [lo, hi]
+        oR1 = o; o += NRT * 2;             //   [t_l, t_u]        (the soft row has no upper side: its slack lives in t_u)
+        oR2 = o; o += NRT * 2;             //   [lambda_l, lambda_u]
+        oR3 = o; o += NRT * 2;             //   [c.z_aff, c.z+]   (F1 -> B2/F2/B1, F2 -> B1)
+        oZ = o; o += NZ;
         oZN = o; o += NZ;
         oGH0 = o; o += NZ;                 // predictor gradient g + C^T e0 (B1 -> B2)
         oA1 = o; o += NZ;                  // C^T e1, C^T e2: the corrector gradient is gh0 + sigma mu a1 + cw a2 (F1 -> B2)
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
 
     // ---- static blocks out ---------------------------------------------------------------------------------------------
     for (int el = hl; el < NRC * NZP; el += 32) w[Ly.oC + el] = sC[el];
-    if (hl < NRT) { w[Ly.oROW + hl * LyT::RW + 0] = sLO[hl]; w[Ly.oROW + hl * LyT::RW + 1] = sHI[hl]; }
+    if (hl < NRT) { w[Ly.oR0 + 2 * hl] = sLO[hl]; w[Ly.oR0 + 2 * hl + 1] = sHI[hl]; }
     double* img = w + Ly.oIMG;
     for (int el = hl; el < NZ * NQP; el += 32) {
         const int c = el / NQP, r = el - c * NQP;
@@ -423,8 +425,9 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
             }
         }
         if (r < NRT) {
-            double* rp = w + Ly.oROW + r * LyT::RW;
-            rp[2] = tl; rp[3] = tu; rp[4] = ll; rp[5] = lu; rp[6] = 0.0; rp[7] = 0.0;
+            w[Ly.oR1 + 2 * r] = tl; w[Ly.oR1 + 2 * r + 1] = tu;
+            w[Ly.oR2 + 2 * r] = ll; w[Ly.oR2 + 2 * r + 1] = lu;
+            w[Ly.oR3 + 2 * r] = 0.0; w[Ly.oR3 + 2 * r + 1] = 0.0;
         }
         sE[r] = -(ll - lu);
     }
@@ -451,9 +454,6 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
 #ifndef QP_WAVES_PER_EU
 #define QP_WAVES_PER_EU 2
 #endif
-#ifndef QP_F_DEPTH
-#define QP_F_DEPTH 1   // stages of look-ahead of the control-chain loads in the forward sweeps (1 or 2)
-#endif
 
 // =========================================================================================================================
 // k_qp_ipm
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     int32_t* __restrict__ last_iter) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
-                  LC0 = LyT::LC0, KS = LyT::KS, RW = LyT::RW;
+                  LC0 = LyT::LC0, KS = LyT::KS;
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS, MRP_MAX = qp_even_c(MR_MAX);
     constexpr int NRC_MAX = NQ + MR_MAX + 1;
     static_assert(MRT < 0 || NX + NRC_MAX <= NL, "one lane per constraint row");
@@ -474,9 +474,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
     constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
     constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
-    constexpr int F_DEPTH = QP_F_DEPTH;
     constexpr int CST_MAX = NRC_MAX * NZP, CST_PF = (CST_MAX / 2 + 31) / 32;   // general rows staged by the forward sweeps
-    static_assert(CST_MAX <= 3 * NX * NX, "the staged rows reuse the P / Hxx buffers, idle outside B1");
+    constexpr int W_N2 = NQ * KS / 2, WST_PF = (W_N2 + 31) / 32;                 // ... and the factor block
+    // (staged in LDS by the other sweeps, in the buffers that only the factorisation sweep uses)
 #ifdef QP_PROFILE
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_readcyclecounter();
@@ -496,10 +496,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const int c_n2 = (Ly.NRC * NZP) >> 1;   // ... and of the general rows
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
-    constexpr int O_TD = IMG_MAX, O_GD = O_TD + NZ * NQP, O_D = O_GD + NQ * MRP_MAX, O_E = O_D + NL, O_LAM = O_E + NL,
+    // [image | D | E | -- buffers of the factorisation sweep only: TD GD Lambda G Wt Hxx P P -- | vectors]
+    constexpr int O_D = IMG_MAX, O_E = O_D + NL, O_TD = O_E + NL, O_GD = O_TD + NZ * NQP, O_LAM = O_GD + NQ * MRP_MAX,
                   O_G = O_LAM + qp_even_c(NQ * NQ), O_WT = O_G + NQ * WS2, O_HXX = O_WT + (NX + 1) * NQP, O_PA = O_HXX + NX * NX,
-                  O_PB2 = O_PA + NX * NX, O_PVA = O_PB2 + NX * NX, O_PVB = O_PVA + NX, O_PB = O_PVB + NX, O_Q = O_PB + NX,
-                  O_ZU = O_Q + NX, O_XB = O_ZU + NQP, O_RHO = O_XB + 2 * NX, O_WV = O_RHO + NQP, HALF_D = O_WV + NQP;
+                  O_PB2 = O_PA + NX * NX, O_PVA = O_PB2 + NX * NX, O_PVB = O_PVA + NX, O_PB = O_PVB + NX,
+                  O_ZU = O_PB + NX, O_XB = O_ZU + NQP, O_RHO = O_XB + 2 * NX, O_WV = O_RHO + NQP, HALF_D = O_WV + NQP;
     __shared__ __attribute__((aligned(16))) double smem[2 * HALF_D];
     __shared__ unsigned char triUi[NTRI_U], triUj[NTRI_U], triXi[NTRI_X], triXj[NTRI_X];
     double* const sIMG = smem + half * HALF_D;
@@ -518,7 +519,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sG = sIMG + O_G;
     double* const sWT = sIMG + O_WT;
     double* const sHXX = sIMG + O_HXX;
-    double* const sCst = sIMG + O_HXX;   // forward sweeps only
+    static_assert(CST_MAX + 2 * NQ * KS <= O_PVA - O_TD, "staging area of the forward sweeps");
+    double* const sCst = sIMG + O_TD;                      // forward sweeps only: general rows ...
+    double* const sWstA = sIMG + O_TD + CST_MAX;           // ... and the factor block, double-buffered (B2: single)
+    double* const sWstB = sIMG + O_TD + CST_MAX + NQ * KS;
     double* const sPB = sIMG + O_PB;
     double* const sZU = sIMG + O_ZU;
     double* const sRho = sIMG + O_RHO;
@@ -537,7 +541,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         triXi[e] = (unsigned char)i;
         triXj[e] = (unsigned char)(i + rem);
     }
-    for (int el = hl; el < (NX + 1) * NQP; el += 32) sWT[el] = 0.0;  // the pad entries stay zero
 
     const double* xb0 = xg + (size_t)b * (N + 1) * NX;
     const double* ub0 = ug + (size_t)b * N * NU;
@@ -646,8 +649,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
 #pragma unroll
                 for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
-                const dbl2* rp = reinterpret_cast<const dbl2*>(w + Ly.oROW + hr * RW);
-                const dbl2 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+                const dbl2 r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr], r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr],
+                           r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr], r3 = reinterpret_cast<const dbl2*>(w + Ly.oR3)[hr];
                 rs.lo = r0.x; rs.hi = r0.y; rs.tl = r1.x; rs.tu = r1.y; rs.ll = r2.x; rs.lu = r2.y;
                 czar = r3.x; cznr = r3.y;
                 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
@@ -673,9 +676,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     const QpDir rd = qp_row_dir<false>(rs, soft, wsoft, cznr, sigmu, corr_w, czar, &rr_, &s1_, &s2_, nullptr, nullptr);
                     rs.tl += alpha * rd.dtl; rs.ll += alpha * rd.dll;
                     rs.tu += alpha * rd.dtu; rs.lu += alpha * rd.dlu;
-                    dbl2* rp = reinterpret_cast<dbl2*>(w + Ly.oROW + hr * RW);
-                    rp[1] = dbl2{rs.tl, rs.tu};
-                    rp[2] = dbl2{rs.ll, rs.lu};
+                    reinterpret_cast<dbl2*>(w + Ly.oR1)[hr] = dbl2{rs.tl, rs.tu};
+                    reinterpret_cast<dbl2*>(w + Ly.oR2)[hr] = dbl2{rs.ll, rs.lu};
                     double Dr;
                     sE[hr] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
                     sD[hr] = Dr;
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         if (hc <= NX) {
 #pragma unroll
                             for (int i = 0; i < NQ; i++) sWT[hc * NQP + i] = col[i];
+                            if (NQP > NQ) sWT[hc * NQP + NQ] = 0.0;   // (the other sweeps stage their blocks over this buffer)
                         }
 #pragma unroll
                         for (int i = 0; i < NQ; i++) w[Ly.oW + i * KS + hc] = col[i];
@@ -848,91 +851,86 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         //                 corrector gradient gh0 + sigma mu a1 + cw a2 -- B2 then never touches the rows or the Jacobian.
         // F2 (corrector): stores z+ and c.z+ of every row.
         // Returns the largest ratio -d/v over all slacks and multipliers (its reciprocal is the step to the boundary).
-        // The loads of the control chain run TWO stages ahead (two register sets, the loop unrolled by two) -- a forward
-        // stage is a few hundred instructions, shorter than the memory latency under load; rows and Jacobian, needed later
-        // in the stage, one stage ahead.
-        struct FSet {
-            double Wr[NX + 1];  // factor row i: [W_i | w_i]
-            double Lt[NQ];      // column i of L^-1
-            double bi;
-        };
-        struct FRow {
-            dbl2 Cs[CST_PF];    // this lane's 16-byte pieces of the general rows (staged through LDS)
-            dbl2 r0, r1, r2;
-            double cza, wsoft;
-        };
-        // n doubles from a 16-byte aligned source, with 16-byte loads and NO over-read: a register that a pending load
-        // will write but nobody reads is "free" to the allocator, and its reuse forces a vmcnt(0) right there
-        auto load_n = [&](double* dst, const double* src, auto n_tag) {
-            constexpr int n = decltype(n_tag)::value;
-            const dbl2* s2 = reinterpret_cast<const dbl2*>(src);
-#pragma unroll
-            for (int j = 0; j < n / 2; j++) { const dbl2 v = s2[j]; dst[2 * j] = v.x; dst[2 * j + 1] = v.y; }
-            if (n & 1) dst[n - 1] = src[n - 1];
-        };
+        // The general rows and the factor block come in as whole 16-byte pieces (every lane useful) and are laid out in LDS,
+        // where the lanes that need a row or a column of them pick it up: narrow per-lane global loads cost the address
+        // unit a full 64-lane instruction each.  The factor block is double-buffered in LDS and committed a stage early, so
+        // the control chain of a stage starts without a hand-off.
         auto sweep_f = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
             double rr = 0.0, S1 = 0.0, S2 = 0.0;
             double *xb = sIMG + O_XB, *xn = sIMG + O_XB + NX;
-            FSet SA, SB;
-            FRow R;
-            auto load_k = [&](FSet& S, int k) {
-                const double* w = stage_ptr(k);
-                load_n(S.Wr, w + Ly.oW + hl_u * KS, std::integral_constant<int, NX + 1>{});
-                const double* wk = w + Ly.oW + LC0 + hl_u;
+            double *wc_ = sWstA, *wn_ = sWstB;    // factor block of this stage / of the next one
+            dbl2 Cs[CST_PF], Ws[WST_PF], r0, r1, r2, r3;
+            double bi, wsoft;
+            auto load_w = [&](int k) {
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(k) + Ly.oW);
 #pragma unroll
-                for (int j = 0; j < NQ; j++) S.Lt[j] = wk[j * KS];
-                S.bi = w[Ly.oIMG + Ly.iB + hl_x];
+                for (int j = 0; j < WST_PF; j++) Ws[j] = s2[min(hl + 32 * j, W_N2 - 1)];
             };
-            auto load_c = [&](FRow& S, int k) {
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(k) + Ly.oC);
+            auto commit_w = [&](double* dst) {
+                dbl2* d2 = reinterpret_cast<dbl2*>(dst);
 #pragma unroll
-                for (int j = 0; j < CST_PF; j++) S.Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
+                for (int j = 0; j < WST_PF; j++) d2[min(hl + 32 * j, W_N2 - 1)] = Ws[j];
             };
-            auto load_r = [&](FRow& S, int k) {
+            auto load_c = [&](int k) {
                 const double* w = stage_ptr(k);
-                const dbl2* rp = reinterpret_cast<const dbl2*>(w + Ly.oROW + hr * RW);
-                S.r0 = rp[0]; S.r1 = rp[1]; S.r2 = rp[2];
-                // (a plain load here gets merged into a 16-byte one whose upper half nobody reads: see load_n)
-                if (CORR) S.cza = __builtin_nontemporal_load(w + Ly.oROW + hr * RW + 6);
-                S.wsoft = w[Ly.oSL];
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oC);
+#pragma unroll
+                for (int j = 0; j < CST_PF; j++) Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
+                bi = w[Ly.oIMG + Ly.iB + hl_x];
             };
-            auto stage_f = [&](FSet& S, int k) {
+            auto load_r = [&](int k) {
+                const double* w = stage_ptr(k);
+                r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr];
+                r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr];
+                r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
+                if (CORR) r3 = reinterpret_cast<const dbl2*>(w + Ly.oR3)[hr];
+                wsoft = w[Ly.oSL];
+            };
+            if (hl < NX) xb[hl] = dx0_reg;
+            load_w(0);
+            load_c(0);
+            load_r(0);
+            commit_w(wc_);
+            load_w(N > 1 ? 1 : 0);
+            lds_fence();
+#pragma unroll 1
+            for (int k = 0; k <= N; k++) {
                 if (CORR) asm volatile("; QPMARK F2_BEGIN"); else asm volatile("; QPMARK F1_BEGIN");
                 const bool last = (k == N);
                 const int kn = k < N ? k + 1 : N;          // past the end the loads repeat the end stage: they stay unconditional
-                const int kk = k + F_DEPTH < N ? k + F_DEPTH : N - 1;  // (there are no factors at the end stage)
+                const int kk = k + 2 < N ? k + 2 : N - 1;  // (there are no factors at the end stage)
                 double* w = stage_ptr(k);
                 // general rows -> LDS (rows for the constraint lanes, columns for a1 / a2)
                 {
                     dbl2* d2 = reinterpret_cast<dbl2*>(sCst);
 #pragma unroll
-                    for (int j = 0; j < CST_PF; j++) d2[min(hl + 32 * j, c_n2 - 1)] = R.Cs[j];
+                    for (int j = 0; j < CST_PF; j++) d2[min(hl + 32 * j, c_n2 - 1)] = Cs[j];
                 }
+                const double bi_k = bi;
+                load_c(kn);
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
-                    double a = S.Wr[NX];
+                    const double* wr_ = wc_ + hl_u * KS;
+                    double a = wr_[NX];
 #pragma unroll
-                    for (int j = 0; j < NX; j++) a = fma(S.Wr[j], xb[j], a);
+                    for (int j = 0; j < NX; j++) a = fma(wr_[j], xb[j], a);
                     if (hl < NQ) sRho[hl] = a;
                 }
-                load_c(R, kn);
                 lds_fence();
                 {
                     double a = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) a = fma(S.Lt[j], sRho[j], a);
+                    for (int j = 0; j < NQ; j++) a = fma(wc_[j * KS + LC0 + hl_u], sRho[j], a);
                     if (hl < NQ) sZU[hl] = last ? 0.0 : -a;
                 }
-                const double bi = S.bi;
-                load_k(S, kk);
                 lds_fence();
                 QPT(CORR ? 10 : 6);
                 // x+ = A x + B u + b
                 if (!last && hl < NX) {
                     const int i = hl < NQ ? hl : hl - NQ;
                     const double u = sZU[i];
-                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi : xb[hl] + dt * u + bi;
+                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi_k : xb[hl] + dt * u + bi_k;
                 }
                 // rows: c.z for the trial point, directions, ratio test
                 {
@@ -943,26 +941,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                     for (int c = 0; c < NX; c++) a = fma(cr[NU + c], xb[c], a);
                     const double cz = hr < NX ? xb[hl_x] : a;
-                    const QpRow rs{R.r0.x, R.r0.y, R.r1.x, R.r1.y, R.r2.x, R.r2.y};
-                    const double wsoft = R.wsoft;
+                    const QpRow rs{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
                     const bool soft = soft_lane && wsoft >= 0.0;
-                    double* rp = w + Ly.oROW + hr * RW;
                     double s1_ = 0.0, s2_ = 0.0;
                     if (!CORR) {
                         double e1, e2;
                         qp_row_dir<true>(rs, soft, wsoft, cz, 0.0, 0.0, cz, &rr, &s1_, &s2_, &e1, &e2);
-                        rp[6] = cz;
+                        w[Ly.oR3 + 2 * hr] = cz;
                         sD[hr] = e1;     // (B1's D / E arrays are free during the forward sweeps)
                         sE[hr] = e2;
                     } else {
-                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, R.cza, &rr, &s1_, &s2_, nullptr, nullptr);
-                        rp[7] = cz;
+                        // (both halves of the pair are read: a loaded-but-unread register would be handed out again while the
+                        //  load is in flight, which costs a full vmcnt(0) at that point)
+                        const double cza = fma(0.0, r3.y, r3.x);
+                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, cza, &rr, &s1_, &s2_, nullptr, nullptr);
+                        w[Ly.oR3 + 2 * hr + 1] = cz;
                         w[Ly.oZN + hz] = hz < NU ? sZU[hl_u] : xb[hl_px];
                     }
                     S1 += row_live ? s1_ : 0.0;
                     S2 += row_live ? s2_ : 0.0;
-                    load_r(R, kn);
+                    load_r(kn);
                 }
+                // next stage's factor block -> its LDS buffer; the one after that -> registers
+                commit_w(wn_);
+                load_w(kk);
                 lds_fence();
                 if (!CORR) {
                     double a1 = 0.0, a2 = 0.0;
@@ -979,26 +981,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     lds_fence();   // (the next stage overwrites the staged rows)
                 }
                 { double* t = xb; xb = xn; xn = t; }
+                { double* t = wc_; wc_ = wn_; wn_ = t; }
                 QPT(CORR ? 11 : 7);
                 if (CORR) asm volatile("; QPMARK F2_END"); else asm volatile("; QPMARK F1_END");
-            };
-            if (hl < NX) xb[hl] = dx0_reg;
-            load_k(SA, 0);
-            load_c(R, 0);
-            load_r(R, 0);
-            if (F_DEPTH == 2) load_k(SB, N > 1 ? 1 : 0);
-            lds_fence();
-            int k = 0;
-            if (F_DEPTH == 2) {
-#pragma unroll 1
-                for (; k + 1 <= N; k += 2) {
-                    stage_f(SA, k);
-                    stage_f(SB, k + 1);
-                }
-                if (k <= N) stage_f(SA, k);
-            } else {
-#pragma unroll 1
-                for (; k <= N; k++) stage_f(SA, k);
             }
             *rr_out = half_max(rr);
             *S1_out = half_sum(S1);
@@ -1019,7 +1004,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         // ---------------- sweep B2: costate recursion of the corrector with the stored factors -------------------------------
         // ~100 instructions per stage: loads run THREE stages ahead (three register sets, the loop unrolled by three)
         {
-            struct BSet { double gh0, a1, a2, pb1, pb2; double LIr[NQ]; double Wc[NQ]; };
+            struct BSet { double gh0, a1, a2, pb1, pb2; dbl2 Ws[WST_PF]; };
             // the two entries of P b this lane needs: controls (i, NQ+i), states (ix, ix-NQ)
             const int ip1 = hl < NU ? hl : hl_px;
             const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
@@ -1031,10 +1016,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 S.pb1 = w[Ly.oPB + ip1];
                 S.pb2 = w[Ly.oPB + ip2];
                 const int kf = k < N ? k : N - 1;   // (there are no factors at the end stage)
-                const double* wf = stage_ptr(kf) + Ly.oW;
-                load_n(S.LIr, wf + hl_u * KS + LC0, std::integral_constant<int, NQ>{});
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(kf) + Ly.oW);
 #pragma unroll
-                for (int t = 0; t < NQ; t++) S.Wc[t] = wf[t * KS + hl_px];
+                for (int j = 0; j < WST_PF; j++) S.Ws[j] = s2[min(hl + 32 * j, W_N2 - 1)];
             };
             auto stage_b2 = [&](BSet& S, int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
@@ -1044,28 +1028,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 const double gh = S.gh0 + sigmu * S.a1 + corr_w * S.a2;
                 if (last) {
                     if (hz >= NU) pvn[hz - NU] = gh;
+                    // (the factor pieces of this set are never used: consume them so that their registers stay reserved)
+                    double sink = 0.0;
+#pragma unroll
+                    for (int j = 0; j < WST_PF; j++) sink = fma(0.0, S.Ws[j].x + S.Ws[j].y, sink);
+                    if (hl == 63 && sink != 0.0) sRho[0] = sink;
                     load_b(S, kp);
                 } else {
-                    // rho = gh_u + B^T q,  q = p_{k+1} + P b ;  wv = L^-1 rho ;  p_k = gh_x + A^T q - W^T wv
+                    // factor block -> LDS;  rho = gh_u + B^T q,  q = p_{k+1} + P b ;  wv = L^-1 rho ;  p_k = gh_x + A^T q - W^T wv
+                    {
+                        dbl2* d2 = reinterpret_cast<dbl2*>(sWstA);
+#pragma unroll
+                        for (int j = 0; j < WST_PF; j++) d2[min(hl + 32 * j, W_N2 - 1)] = S.Ws[j];
+                    }
                     const double q1 = pvc[ip1] + S.pb1, q2 = pvc[ip2] + S.pb2;
                     if (hl < NU) sRho[hl] = gh + cB * q1 + dt * q2;
+                    load_b(S, kp);
                     lds_fence();
                     QPT(8);
                     {
                         double v = 0.0;
 #pragma unroll
-                        for (int j = 0; j < NQ; j++) v = fma(S.LIr[j], sRho[j], v);
+                        for (int j = 0; j < NQ; j++) v = fma(sWstA[hl_u * KS + LC0 + j], sRho[j], v);
                         if (hl < NQ) sWv[hl] = v;
-                        w[Ly.oW + hl_u * KS + NX] = v;   // the corrector's w (F2 reads it with the row)
+                        w[Ly.oW + hl_u * KS + NX] = v;   // the corrector's w (F2 reads it with the block)
                     }
                     lds_fence();
                     if (k > 0 && hz >= NU) {
                         double v = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
 #pragma unroll
-                        for (int t = 0; t < NQ; t++) v = fma(-S.Wc[t], sWv[t], v);
+                        for (int t = 0; t < NQ; t++) v = fma(-sWstA[t * KS + hl_px], sWv[t], v);
                         pvn[hl_px] = v;
                     }
-                    load_b(S, kp);
                 }
                 lds_fence();
                 if (last || k > 0) { double* t2 = pvc; pvc = pvn; pvn = t2; }
