@@ -522,7 +522,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     static_assert(CST_MAX + 2 * NQ * KS <= O_PVA - O_TD, "staging area of the forward sweeps");
     double* const sCst = sIMG + O_TD;                      // forward sweeps only: general rows ...
     double* const sWstA = sIMG + O_TD + CST_MAX;           // ... and the factor block, double-buffered (B2: single)
-    double* const sWstB = sIMG + O_TD + CST_MAX + NQ * KS;
     double* const sPB = sIMG + O_PB;
     double* const sZU = sIMG + O_ZU;
     double* const sRho = sIMG + O_RHO;
@@ -698,19 +697,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     sPB[hl_x] = a;
                     w[Ly.oPB + hl_x] = a;
                 }
-                for (int el = hl; el < NZ * NQP; el += 32) {
+                // (fixed trip counts with clamped indices instead of data-dependent loop bounds: the passes of one loop are
+                //  independent, and only a fully unrolled loop lets the scheduler overlap their LDS round trips)
+#pragma unroll
+                for (int t = 0; t < (NZ * NQP + 31) / 32; t++) {
+                    const int el = min(hl + 32 * t, NZ * NQP - 1);
                     const int r = el % NQP;
                     sTD[el] = sTT[el] * sD[rT0 + (r < NQ ? r : 0)];   // pad entries of Tt are zero
                 }
-                for (int el = hl; el < NQ * MRP; el += 32) {
-                    const int r = el % MRP;
-                    sGD[el] = sGT[el] * sD[rC0 + (r < MR ? r : 0)];
+#pragma unroll
+                for (int t = 0; t < (NQ * MRP_MAX + 31) / 32; t++) {
+                    const int el = hl + 32 * t;
+                    if (el < NQ * MRP) {
+                        const int r = el % MRP;
+                        sGD[el] = sGT[el] * sD[rC0 + (r < MR ? r : 0)];
+                    }
                 }
                 lds_fence();
                 QPT(1);
                 // -- H + C^T D C by blocks, with B^T P B / B^T P A folded into the u rows
                 if (!last) {
-                    for (int el = hl; el < NTRI_U; el += 32) {
+#pragma unroll
+                    for (int t = 0; t < (NTRI_U + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NTRI_U - 1);   // (lanes past the end repeat the last element)
                         const int i = triUi[el], j = triUj[el];
                         double a = pdot(sTT + i * NQP, sTD + j * NQP, NQP / 2);
                         if (i == j) a += sSC[0];
@@ -720,7 +729,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         sLam[i * NQ + j] = a;
                         sLam[j * NQ + i] = a;
                     }
-                    for (int el = hl; el < NQ * NX; el += 32) {
+#pragma unroll
+                    for (int t = 0; t < (NQ * NX + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NQ * NX - 1);
                         const int i = el / NX, jx = el - i * NX;
                         double a = pdot(sTT + i * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                         // B^T P A: left block c P11 + dt P21 ; right block dt (c P11 + dt P21) + c P12 + dt P22
@@ -735,7 +746,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 }
                 {
                     const double dnn = sD[rNN];
-                    for (int el = hl; el < NTRI_X; el += 32) {
+#pragma unroll
+                    for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NTRI_X - 1);
                         const int ix = triXi[el], jx = triXj[el];
                         double a = pdot(sTT + (NU + ix) * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                         a = fma(sGN[ix] * dnn, sGN[jx], a);
@@ -801,7 +814,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     QPT(3);
                     if (k > 0) {
                         // P_k = Hxx + A^T P A - W^T W (upper triangle, mirrored into the other buffer) and p_k
-                        for (int el = hl; el < NTRI_X; el += 32) {
+#pragma unroll
+                        for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
+                            const int el = min(hl + 32 * t, NTRI_X - 1);
                             const int i = triXi[el], j = triXj[el];
                             double a = sHXX[i * NX + j];
                             // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]
@@ -858,8 +873,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         auto sweep_f = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
             double rr = 0.0, S1 = 0.0, S2 = 0.0;
-            double *xb = sIMG + O_XB, *xn = sIMG + O_XB + NX;
-            double *wc_ = sWstA, *wn_ = sWstB;    // factor block of this stage / of the next one
+            // (ping-pong buffers as offsets, not pointers: an offset can go through an optimisation barrier without the LDS
+            //  address space being lost)
+            int o_xb = O_XB, o_xn = O_XB + NX;
+            int o_wc = O_TD + CST_MAX, o_wn = O_TD + CST_MAX + NQ * KS;    // factor block of this stage / of the next one
             dbl2 Cs[CST_PF], Ws[WST_PF], r0, r1, r2, r3;
             double bi, wsoft;
             auto load_w = [&](int k) {
@@ -877,7 +894,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oC);
 #pragma unroll
                 for (int j = 0; j < CST_PF; j++) Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
-                bi = w[Ly.oIMG + Ly.iB + hl_x];
             };
             auto load_r = [&](int k) {
                 const double* w = stage_ptr(k);
@@ -886,14 +902,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
                 if (CORR) r3 = reinterpret_cast<const dbl2*>(w + Ly.oR3)[hr];
                 wsoft = w[Ly.oSL];
+                bi = w[Ly.oIMG + Ly.iB + hl_x];
             };
-            if (hl < NX) xb[hl] = dx0_reg;
+            if (hl < NX) sIMG[o_xb + hl] = dx0_reg;
             load_w(0);
             load_c(0);
             load_r(0);
-            commit_w(wc_);
+            commit_w(sIMG + o_wc);
             load_w(N > 1 ? 1 : 0);
             lds_fence();
+            // Everything in flight lands before the loop starts (stage 0 needs it at once anyway).  Without this, a register
+            // that is still "pending" on loop entry -- a spill reload in the preheader is enough -- makes the compiler put
+            // its wait INSIDE the loop body, where it then drains the prefetch queue on every stage.
+            asm volatile("" : "+v"(o_wc), "+v"(o_wn), "+v"(o_xb), "+v"(o_xn));   // (reloaded here, not in the preheader)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 #pragma unroll 1
             for (int k = 0; k <= N; k++) {
                 if (CORR) asm volatile("; QPMARK F2_BEGIN"); else asm volatile("; QPMARK F1_BEGIN");
@@ -901,13 +923,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 const int kn = k < N ? k + 1 : N;          // past the end the loads repeat the end stage: they stay unconditional
                 const int kk = k + 2 < N ? k + 2 : N - 1;  // (there are no factors at the end stage)
                 double* w = stage_ptr(k);
+                double *const xb = sIMG + o_xb, *const xn = sIMG + o_xn, *const wc_ = sIMG + o_wc, *const wn_ = sIMG + o_wn;
                 // general rows -> LDS (rows for the constraint lanes, columns for a1 / a2)
                 {
                     dbl2* d2 = reinterpret_cast<dbl2*>(sCst);
 #pragma unroll
                     for (int j = 0; j < CST_PF; j++) d2[min(hl + 32 * j, c_n2 - 1)] = Cs[j];
                 }
-                const double bi_k = bi;
                 load_c(kn);
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
@@ -930,7 +952,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 if (!last && hl < NX) {
                     const int i = hl < NQ ? hl : hl - NQ;
                     const double u = sZU[i];
-                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi_k : xb[hl] + dt * u + bi_k;
+                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi : xb[hl] + dt * u + bi;
                 }
                 // rows: c.z for the trial point, directions, ratio test
                 {
@@ -980,8 +1002,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     w[Ly.oA2 + hz] = a2;
                     lds_fence();   // (the next stage overwrites the staged rows)
                 }
-                { double* t = xb; xb = xn; xn = t; }
-                { double* t = wc_; wc_ = wn_; wn_ = t; }
+                { const int t = o_xb; o_xb = o_xn; o_xn = t; }
+                { const int t = o_wc; o_wc = o_wn; o_wn = t; }
                 QPT(CORR ? 11 : 7);
                 if (CORR) asm volatile("; QPMARK F2_END"); else asm volatile("; QPMARK F1_END");
             }
