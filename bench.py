@@ -24,6 +24,9 @@ import time
 
 import numpy as np
 
+# one hardware queue per sub-batch stream (the HIP default of 4 makes two of them share a queue and serialise)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -107,6 +110,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='instances per GPU')
+    ap.add_argument('--graphs', type=int, default=0,
+                    help='1: replay each sub-batch step as a captured hipGraph (measured: no gain at 1-2 streams, see DESIGN.md)')
     ap.add_argument('--streams', type=int, default=2,
                     help='sub-batches per GPU, each on its own HIP stream (fills the tail of the slowest instances)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -164,21 +169,29 @@ def main():
         subs.append(sb)
     gather_in = torch.empty((B, nu + 1), dtype=torch.float64, device=dev)
 
+    def sub_step(sb, first):
+        """One closed-loop step of one sub-batch, entirely on its stream, state updated in place (graph-capturable)."""
+        sv = sb.solver
+        if not first:
+            sv.guess_correction(sb.xg, sb.ug)                                     # controller.py:226-231
+        xt, ut, st, it = sv.solve(sb.x_sim, sb.xg, sb.ug, sb.p, out=sb.out)      # controller.py:136-167
+        accept = (st == 0).to(torch.int32)                                        # NaiveController.step (:279-283)
+        _, _, u_apply = sv.provide_control(accept, xt, ut, sb.xg, sb.ug)          # controller.py:169-184 (xg, ug in place)
+        xn, _ = sv.plant_step(sb.x_sim, u_apply)                                  # env_model.py:192-206 (nominal plant)
+        sb.x_sim.copy_(xn)
+        sb.iters.add_(it.sum())
+        sb.fails.add_((st != 0).sum())
+        if use_dist:
+            sb.payload[:, :nu] = u_apply
+            sb.payload[:, nu] = st.to(torch.float64)
+
     def step(first):
         for sb in subs:
-            sv = sb.solver
             with torch.cuda.stream(sb.stream):
-                if not first:
-                    sv.guess_correction(sb.xg, sb.ug)                                 # controller.py:226-231
-                xt, ut, st, it = sv.solve(sb.x_sim, sb.xg, sb.ug, sb.p, out=sb.out)  # controller.py:136-167
-                accept = (st == 0).to(torch.int32)                                    # NaiveController.step (:279-283)
-                sb.xg, sb.ug, u_apply = sv.provide_control(accept, xt, ut, sb.xg, sb.ug)   # controller.py:169-184
-                sb.x_sim, _ = sv.plant_step(sb.x_sim, u_apply)                        # env_model.py:192-206 (nominal plant)
-                sb.iters.add_(it.sum())
-                sb.fails.add_((st != 0).sum())
-                if use_dist:
-                    sb.payload[:, :nu] = u_apply
-                    sb.payload[:, nu] = st.to(torch.float64)
+                if sb.graph is not None and not first:
+                    sb.graph.replay()       # the ~25 launches of one sub-batch step as ONE hipGraphLaunch
+                else:
+                    sub_step(sb, first)
         if use_dist:                                                                  # the single result gather (SURVEY 8e)
             for sb in subs:
                 sb.stream.synchronize()
@@ -196,9 +209,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for sb in subs:
+        sb.graph = None
     for i in range(args.warmup):
         step(first=(i == 0))
     barrier()
+    # hipGraph capture of one sub-batch step (after the warm-up: every workspace exists, nothing allocates or syncs).
+    # With S sub-batches in flight the host has to issue S x 25 launches per step; as graphs that is S launches, and the
+    # streams drift apart so that the long tail of one sub-batch's QP kernel is filled by the bulk of another's.
+    if args.graphs and args.warmup >= 2:
+        try:
+            for sb in subs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=sb.stream, capture_error_mode='relaxed'):
+                    sub_step(sb, False)
+                sb.graph = g
+        except Exception as e:      # report, fall back to eager launches
+            print(f'[bench] graph capture failed ({type(e).__name__}: {e}); eager launches', file=sys.stderr)
+            for sb in subs:
+                sb.graph = None
+        barrier()
     for sb in subs:
         sb.iters.zero_()
         sb.fails.zero_()
@@ -226,26 +256,30 @@ def main():
             ugf = torch.cat([sb.ug for sb in subs]); pf = torch.cat([sb.p for sb in subs])
         torch.cuda.synchronize()
         sv.enable_timing(True)
-        acc = np.zeros(4)
+        acc = np.zeros(6)
         probes = 5
         for _ in range(probes):
             with torch.cuda.stream(st_):
                 sv.guess_correction(xgf, ugf)
                 sv.solve(xs, xgf, ugf, pf)
             tm = sv.timing()
-            acc += [tm['time_lin'], tm['time_nn'], tm['time_qp'], tm['time_tot']]
+            acc += [tm['time_lin'], tm['time_nn'], tm['time_qp'], tm['time_tot'], tm['time_qp_setup'], tm['time_qp_ipm']]
         acc /= probes
         alg = algorithmic_bytes(prob.nq, N) * B
-        ach = alg / acc[2] / 1e9
+        ach = alg / acc[5] / 1e9
         # HBM bytes per launch from the committed PMC passes of the same kernel / workload (profiles/, scripts/pmc_traffic.py);
         # counters cannot be read from inside this process
-        traffic = None
+        traffic, traffic_rate = None, None
         tf = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         if os.path.exists(tf) and B == B_PER_GPU:
-            traffic = json.load(open(tf))['traffic_bytes_per_launch']
+            tj = json.load(open(tf))
+            traffic = tj['traffic_bytes_per_launch']
+            # (same-run ratio: the PMC passes time their own launches, whose iteration counts differ from this probe's)
+            traffic_rate = tj.get('traffic_GBps_in_pmc_run')
         roof = {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
-                'kernel_ms': {'linearise': acc[0] * 1e3, 'mlp': acc[1] * 1e3, 'qp': acc[2] * 1e3, 'solve_total': acc[3] * 1e3},
+                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_GBps_in_pmc_run': traffic_rate,
+                'kernel_ms': {'linearise': acc[0] * 1e3, 'mlp': acc[1] * 1e3, 'qp_setup': acc[4] * 1e3, 'qp_ipm': acc[5] * 1e3,
+                              'solve_total': acc[3] * 1e3},
                 'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={B}, alone on the GPU'}
 
     cpu = None
@@ -262,7 +296,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'C1: Z1-class 6-DoF, N=30, 4096 instances/GPU, controller st (soft terminal NN row, '
                                    'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',
-                       'batch_per_gpu': B, 'horizon': N, 'controller': CONTROLLER, 'streams_per_gpu': S,
+                       'batch_per_gpu': B, 'horizon': N, 'controller': CONTROLLER, 'streams_per_gpu': S, 'hip_graphs': bool(subs[0].graph is not None),
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
                        'failed_instance_steps': fails},
             'roofline': roof, 'cpu_baseline': cpu,

@@ -233,6 +233,9 @@ void* smpc_stream(smpc_handle* h);
  * (controller.py:123-124,192-193).  Only valid when timing was enabled. */
 int smpc_enable_timing(smpc_handle* h, int on);
 int smpc_get_timing(smpc_handle* h, float* ms4);
+/* Split of ms[2] of smpc_get_timing: ms2[0] = k_qp_setup (stage records + initial point), ms2[1] = k_qp_ipm (the interior-
+ * point iterations) -- the per-kernel durations rocprofv3 --kernel-trace reports (acados: time_qp_solver_call). */
+int smpc_get_qp_timing(smpc_handle* h, float* ms2);
 
 #ifdef __cplusplus
 }

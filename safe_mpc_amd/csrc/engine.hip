@@ -254,11 +254,13 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     if (h->desc.n_rows == 6) {
         hipLaunchKernelGGL((k_qp_setup<NQ, 6>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,
                            h->d_ev, h->d_ws, bstride);
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));
         hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
                            xo, uo, st, it, order, h->d_last_it);
     } else {
         hipLaunchKernelGGL((k_qp_setup<NQ, -1>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,
                            h->d_ev, h->d_ws, bstride);
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));
         hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
                            xo, uo, st, it, order, h->d_last_it);
     }
@@ -671,6 +673,16 @@ int smpc_get_timing(smpc_handle* h, float* ms4) {
     HIPCHK(h, hipEventElapsedTime(&ms4[1], h->ev_t[1], h->ev_t[2]));
     HIPCHK(h, hipEventElapsedTime(&ms4[2], h->ev_t[2], h->ev_t[3]));
     HIPCHK(h, hipEventElapsedTime(&ms4[3], h->ev_t[0], h->ev_t[3]));
+    return SMPC_OK;
+}
+
+int smpc_get_qp_timing(smpc_handle* h, float* ms2) {
+    if (!h || !ms2) return SMPC_EINVAL;
+    if (!h->timing) return fail(h, SMPC_ESTATE, "timing not enabled");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
+    HIPCHK(h, hipEventElapsedTime(&ms2[0], h->ev_t[2], h->ev_t[4]));
+    HIPCHK(h, hipEventElapsedTime(&ms2[1], h->ev_t[4], h->ev_t[3]));
     return SMPC_OK;
 }
 

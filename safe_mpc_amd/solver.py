@@ -93,7 +93,10 @@ class BatchedOcpSolver:
     def timing(self):
         ms = (C.c_float * 4)()
         self._chk(self.L.smpc_get_timing(self.h, ms))
-        return {'time_lin': ms[0] * 1e-3, 'time_nn': ms[1] * 1e-3, 'time_qp': ms[2] * 1e-3, 'time_tot': ms[3] * 1e-3}
+        q = (C.c_float * 2)()
+        self._chk(self.L.smpc_get_qp_timing(self.h, q))
+        return {'time_lin': ms[0] * 1e-3, 'time_nn': ms[1] * 1e-3, 'time_qp': ms[2] * 1e-3, 'time_tot': ms[3] * 1e-3,
+                'time_qp_setup': q[0] * 1e-3, 'time_qp_ipm': q[1] * 1e-3}
 
     # -- argument plumbing -----------------------------------------------------------------------------------------------
     def _prep(self, arrs, shapes, dtypes=None):
