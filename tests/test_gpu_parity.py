@@ -230,3 +230,23 @@ def test_instance_bounds_parity():
     s.set_instance_bounds(None, None)
     xa1, ua1, _, _ = s.solve(x0, xg, ug, p)
     assert np.array_equal(ua1, ua0)
+
+
+@pytest.mark.parametrize('nq,B,drop_rows', [(6, 1, 0), (6, 33, 0), (5, 17, 0), (6, 9, 2)])
+def test_kernel_instantiations_and_odd_batches(nq, B, drop_rows):
+    """k_qp_ipm pairs two instances per wavefront: odd batches leave a lone half-wave; nq = 5 (the reference's default
+    n_dofs, config.yaml:10) and a row count other than the specialised 6 take other template instantiations."""
+    par, prob, net = make_problem('st', 'ext', N=12, nq=nq)
+    if drop_rows:
+        prob.desc.n_rows -= drop_rows          # the last capsule pairs go: the runtime-row-count kernel
+    s, o = _solver(prob, net), _oracle(prob, net)
+    x0 = sample_instances(prob, B, seed=5, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    xa, ua, sa, ia = s.solve(x0, xg, ug, p)
+    xb, ub, sb, ib = o.solve_batch(x0, xg, ug, p)
+    assert np.array_equal(sa, sb)
+    ok = sb == 0
+    assert ok.sum() >= B - 1
+    assert np.abs(ia[ok] - ib[ok]).max() <= 2
+    assert np.abs(ua[ok] - ub[ok]).max() < 1e-4 * (1 + np.abs(ub[ok]).max())
+    assert np.abs(xa[ok] - xb[ok]).max() < 1e-4
