@@ -233,6 +233,13 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
     return SMPC_OK;
 }
 
+// experiment knob: extra dynamic LDS per block of k_qp_ipm limits how many wavefronts are resident per CU (the rest queue
+// behind the longest-first order and backfill)
+static size_t qp_pad_lds() {
+    static const size_t v = [] { const char* e = getenv("SMPC_QP_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    return v;
+}
+
 template <int NQ>
 int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
                  double* xo, double* uo, int32_t* st, int32_t* it) {
@@ -255,7 +262,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         hipLaunchKernelGGL((k_qp_setup<NQ, 6>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,
                            h->d_ev, h->d_ws, bstride);
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));
-        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
+        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
                            xo, uo, st, it, order, h->d_last_it);
     } else {
         hipLaunchKernelGGL((k_qp_setup<NQ, -1>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,

@@ -1127,18 +1127,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // ---- full SQP step (FIXED_STEP, parser.py:139), applying the last IPM step if it is still pending -------------------
     bool bad = false;
     const double a_fin = pending ? alpha : 0.0;
-#pragma unroll 4
-    for (int k = 0; k <= N; k++) {
-        const double* w = ws + (size_t)k * Ly.stride;
-        const double z = w[Ly.oZ + hz], zn = w[Ly.oZN + hz];
-        const int ku = k < N ? k : N - 1;
-        const double base = hl < NU ? ub0[(size_t)ku * NU + hl_u] : xb0[(size_t)k * NX + hl_px];
-        const double v = base + z + a_fin * (zn - z);
-        if (hl < NU) {
-            if (k < N) { u_out[((size_t)b * N + k) * NU + hl] = v; bad |= !(v == v); }
-        } else if (hl < NZ) {
-            x_out[((size_t)b * (N + 1) + k) * NX + hl - NU] = v;
-            bad |= !(v == v);
+    // (chunks of 8 stages: all loads of a chunk are issued before its first -- conditional -- store, so the chunk costs one
+    //  memory latency instead of eight)
+    constexpr int EP_CH = 8;
+    for (int k0 = 0; k0 <= N; k0 += EP_CH) {
+        double zz[EP_CH], zzn[EP_CH], bb[EP_CH];
+#pragma unroll
+        for (int j = 0; j < EP_CH; j++) {
+            const int k = k0 + j <= N ? k0 + j : N;
+            const double* w = ws + (size_t)k * Ly.stride;
+            zz[j] = w[Ly.oZ + hz];
+            zzn[j] = w[Ly.oZN + hz];
+            const int ku = k < N ? k : N - 1;
+            bb[j] = hl < NU ? ub0[(size_t)ku * NU + hl_u] : xb0[(size_t)k * NX + hl_px];
+        }
+#pragma unroll
+        for (int j = 0; j < EP_CH; j++) {
+            const int k = k0 + j;
+            const double v = bb[j] + zz[j] + a_fin * (zzn[j] - zz[j]);
+            if (k <= N) {
+                if (hl < NU) {
+                    if (k < N) { u_out[((size_t)b * N + k) * NU + hl] = v; bad |= !(v == v); }
+                } else if (hl < NZ) {
+                    x_out[((size_t)b * (N + 1) + k) * NX + hl - NU] = v;
+                    bad |= !(v == v);
+                }
+            }
         }
     }
     const bool any_bad = half_max(bad ? 1.0 : 0.0) > 0.0;
