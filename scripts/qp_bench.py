@@ -16,7 +16,7 @@ N = prob.N
 xg = np.repeat(x0[:, None, :], N + 1, axis=1); ug = np.zeros((B, N, 6)); p = np.zeros((B, N + 1, 5))
 p[:, :, :3], p[:, :, 3], p[:, :, 4] = prob.ee_ref, par.alpha, 1.0
 x = x0
-for i in range(5):
+for i in range(int(os.environ.get('SMPC_WARM', '5'))):
     xo, uo, st, it = s.solve(x, xg, ug, p)
     xg, ug, ua = s.provide_control((st == 0).astype(np.int32), xo, uo, xg, ug)
     x, _ = s.plant_step(x, ua)
