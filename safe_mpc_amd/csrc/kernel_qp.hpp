@@ -10,25 +10,33 @@
 //                half-uniform and the SIMT exec mask does the rest (a converged half idles until its twin is done;
 //                longest-first dispatch pairs instances with similar iteration counts).
 // Per IPM iteration a half-wave walks the horizon four times
-//   B1  backward: apply the previous step, barrier weights, H + C^T D C, Riccati factorisation, predictor costate
-//   F1  forward : predictor roll-out, affine step length, centring parameter
-//   B2  backward: corrector gradient, costate recursion with the stored factors
-//   F2  forward : corrector roll-out, step length, step directions of every row
-// Data movement (v5; v3/v4 in the git history staged whole stage records through LDS):
-//   * everything a single lane owns -- the bounds, slacks and multipliers of "its" constraint row, its row or column of
-//     the constraint Jacobian, its row of the feedback gain -- goes from the HBM workspace straight into that lane's
-//     registers, re-loaded for the next stage right after its last use in this one (a full stage of latency cover);
-//   * LDS holds only what lanes exchange: the vectors of the recursions (x, u, costate, row coefficients) and, in B1, the
-//     matrices of the factorisation (transposed Jacobian image, P ping-pong, Lambda, G, W);
-//   * the factorisation stores the gain in closed form (K = Lambda^-1 G, k; W = L^-1 G and L^-1 for the costate -- the
-//     symmetric two-step form keeps the corrector solve as accurate as substitution), so the three light sweeps are
-//     lane-parallel matrix-vector products separated by wave-scope LDS fences (no s_barrier, no vmcnt drain);
+//   B1  backward: apply the previous step, barrier weights, H + C^T D C, Cholesky, W = L^-1 [G | rho], L^-1, P_k,
+//                 predictor costate and gradient gh0
+//   F1  forward : predictor roll-out u = -L^-T (W x + w), ratio test, centring; c.z_aff of every row and the vectors
+//                 a1 = C^T e1, a2 = C^T e2 (the corrector gradient is gh0 + sigma mu a1 + cw a2)
+//   B2  backward: costate recursion of the corrector with the stored factors (touches neither rows nor Jacobian)
+//   F2  forward : corrector roll-out, ratio test, z+ and c.z+ of every row (B1 rebuilds the row steps from them)
+// Data movement (v8; the git history and DESIGN.md section 4 have v1-v7 and what each taught):
+//   * what a single lane owns -- the bounds, slacks and multipliers of "its" constraint row, its column of [G | rho | I] --
+//     goes from the HBM workspace straight into that lane's registers, re-loaded for the next stage right after its
+//     last use in this one;
+//   * what many lanes read -- the general rows (a row per constraint lane, a column per variable lane), the factor block,
+//     the B1 image -- arrives as whole 16-byte pieces (every lane useful: a narrow per-lane global load costs the address
+//     unit a full 64-lane instruction) and is laid out in LDS, double-buffered and committed a stage early in the
+//     forward sweeps, over the buffers that only B1 uses;
+//   * LDS otherwise holds the vectors of the recursions (x, u, costate, row coefficients) and B1's matrices (transposed
+//     Jacobian image, scaled copy, P ping-pong, Lambda, G, W^T); cross-lane hand-offs are wave-scope LDS fences (no
+//     s_barrier, no vmcnt drain);
+//   * the corrector costate keeps the symmetric two-step form W^T (L^-1 rho) and u = -L^-T (W x + w): as accurate as
+//     substitution; the closed-form Lambda^-1 rho loses the IPM's last iterations to cancellation;
 //   * every vector-memory instruction of a stage is unconditional and straight-line (lanes beyond an array's length
 //     duplicate its last entry -- same loads, same arithmetic, same stores to the same address -- stage indices are
-//     clamped instead of branched on, the horizon's end stage is peeled off): gfx9
-//     counts loads and stores in ONE in-order vmcnt, and the compiler can only wait for "all but the n youngest" when
-//     n is the same on every path -- a single conditional load otherwise turns each wait into vmcnt(0) and serialises
-//     the stage on the loads it has just issued for the next one.
+//     clamped instead of branched on, the horizon's end stage is peeled off): gfx9 counts loads and stores in ONE
+//     in-order vmcnt, and the compiler can only wait for "all but the n youngest" when n is the same on every path -- a
+//     single conditional load otherwise turns each wait into vmcnt(0) and serialises the stage on the loads it has just
+//     issued for the next one (same effect: a loaded register nobody reads, a spill reload in a loop preheader, a
+//     pointer that went through inline asm -- see the comments at load_n, stage_ptr and before the forward loops);
+//   * prefetch depth by sweep: B1 one stage, F1/F2 one stage for rows and two for the staged blocks, B2 three stages.
 // The double integrator's A, B are never stored (env_model.py:63-67): every product with them is expanded in closed form.
 //
 // The algorithm is the one restated in oracle/smpc_oracle.cpp::qp_ipm (same initial point, Mehrotra rule, step rule and
