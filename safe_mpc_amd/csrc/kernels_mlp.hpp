@@ -50,7 +50,32 @@ __global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const flo
     for (int i = 0; i < 16; i++) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
     const float* arow = A + (size_t)(m0 + li) * K + 4 * lh;
     const float* bcol = Bm + (size_t)(4 * lh) * N + n0 + li;
-    for (int kc = 0; kc < K; kc += 8) {
+    // One k-step = 8 MFMAs, shorter than an L2 round trip for its operands: the main loop takes four k-steps at a time and
+    // issues all their loads (4 x (1 + 8)) before the 32 MFMAs that consume them.
+    auto kstep = [&](const f32x4 av, const float* b0, const float* b1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], b0[r], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], b1[r], acc1, 0, 0, 0);
+        }
+    };
+    int kc = 0;
+    for (; kc + 32 <= K; kc += 32) {
+        f32x4 av[4];
+        float b0[4][4], b1[4][4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            av[s4] = *reinterpret_cast<const f32x4*>(arow + kc + 8 * s4);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                b0[s4][r] = bcol[(size_t)(kc + 8 * s4 + r) * N];
+                b1[s4][r] = bcol[(size_t)(kc + 8 * s4 + r) * N + 32];
+            }
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) kstep(av[s4], b0[s4], b1[s4]);
+    }
+    for (; kc < K; kc += 8) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(arow + kc);
         float b0[4], b1[4];
 #pragma unroll
@@ -58,11 +83,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const flo
             b0[r] = bcol[(size_t)(kc + r) * N];
             b1[r] = bcol[(size_t)(kc + r) * N + 32];
         }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], b0[r], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[r], b1[r], acc1, 0, 0, 0);
-        }
+        kstep(av, b0, b1);
     }
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
