@@ -117,6 +117,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when its first communicator comes
+    # up: keep the real stdout aside for the result line and send everything else written to fd 1 to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -193,12 +199,17 @@ def main():
                 else:
                     sub_step(sb, first)
         if use_dist:                                                                  # the single result gather
+            # stream-ordered, no host synchronisation: the gather stream waits for the sub-batches, and they wait for the
+            # copy out of their payload buffers before the next step overwrites them
+            cur = torch.cuda.current_stream()
             for sb in subs:
-                sb.stream.synchronize()
+                cur.wait_stream(sb.stream)
             off = 0
             for sb in subs:
                 gather_in[off:off + sb.n] = sb.payload
                 off += sb.n
+            for sb in subs:
+                sb.stream.wait_stream(cur)
             gather_to_root(gather_in, sizes=[B] * world)
 
     def barrier():
@@ -301,7 +312,8 @@ def main():
                        'failed_instance_steps': fails},
             'roofline': roof, 'cpu_baseline': cpu,
         }
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + '\n').encode())
     if use_dist:
         dist.destroy_process_group()
 
