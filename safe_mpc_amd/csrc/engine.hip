@@ -643,9 +643,9 @@ int smpc_plant_step(smpc_handle* h, int B, const double* x, const double* u, con
         if (joints_noisy) { HIPCHK(h, hipMemcpyAsync(wj, joints_noisy, sizeof(smpc_joint) * (size_t)B * nq, hipMemcpyHostToDevice, s)); dj = wj; }
     }
     switch (nq) {
-    case 5: hipLaunchKernelGGL((k_plant_step<5>), dim3((B + 63) / 64), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
-    case 6: hipLaunchKernelGGL((k_plant_step<6>), dim3((B + 63) / 64), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
-    default: hipLaunchKernelGGL((k_plant_step<7>), dim3((B + 63) / 64), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
+    case 5: hipLaunchKernelGGL((k_plant_step<5>), dim3((B + 8) / 9), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
+    case 6: hipLaunchKernelGGL((k_plant_step<6>), dim3((B + 7) / 8), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
+    default: hipLaunchKernelGGL((k_plant_step<7>), dim3((B + 6) / 7), dim3(64), 0, s, h->d_desc, B, dx, du, dj, dn, dxn, due); break;
     }
     HIPCHK(h, hipGetLastError());
     if (!on_device) {

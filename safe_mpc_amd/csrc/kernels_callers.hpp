@@ -126,53 +126,58 @@ __global__ void k_check_nn(const smpc_problem_desc* __restrict__ D, int M, const
     nn_ok[m] = (g >= -tol_safe) && (g <= 1e6 + tol_safe);
 }
 
-// plant step AdamModel.integrate (env_model.py:192-206); one thread per instance
+// plant step AdamModel.integrate (env_model.py:192-206).  NQ + 2 lanes per instance, one inverse-dynamics call each: lane 0
+// tau(q, qd, u), lane 1 the bias h(q, qd), lanes 2.. the columns of M (unit accelerations, no velocity, no gravity) -- the
+// same code with different inputs, so the wavefront does not diverge; lane 0 then solves M a = clamp(tau + noise) - h.
 template <int NQ>
 __global__ __launch_bounds__(64) void k_plant_step(const smpc_problem_desc* __restrict__ D, int B, const double* __restrict__ x,
                              const double* __restrict__ u, const smpc_joint* __restrict__ joints_noisy,
                              const double* __restrict__ tau_noise, double* __restrict__ x_next,
                              double* __restrict__ u_eff) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    constexpr int NX = 2 * NQ;
-    const smpc_joint* J = joints_noisy ? joints_noisy + (size_t)b * NQ : D->joints;
-    const double* xb = x + (size_t)b * NX;
-    double q[NQ], qd[NQ], uu[NQ], zero[NQ], tau[NQ], h[NQ];
+    constexpr int NX = 2 * NQ, RL = NQ + 2, PER = 64 / RL;
+    __shared__ double sm[PER][RL][NQ];
+    const int li = threadIdx.x / RL, role = threadIdx.x % RL;
+    const int b = blockIdx.x * PER + li;
+    const bool live = li < PER && b < B;
+    const int bb = live ? b : 0;
+    const smpc_joint* J = joints_noisy ? joints_noisy + (size_t)bb * NQ : D->joints;
+    const double* xb = x + (size_t)bb * NX;
+    double q[NQ], qd[NQ], qdd[NQ], out[NQ];
+    const bool dyn = role < 2;
 #pragma unroll
-    for (int i = 0; i < NQ; i++) { q[i] = xb[i]; qd[i] = xb[NQ + i]; uu[i] = u[(size_t)b * NQ + i]; zero[i] = 0.0; }
-    rnea_world<NQ, double>(J, D->gravity, q, qd, uu, tau);
-    rnea_world<NQ, double>(J, D->gravity, q, qd, zero, h);
-    double M[NQ][NQ];
-    const double g0[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int j = 0; j < NQ; j++) {
-        double e[NQ], col[NQ];
-#pragma unroll
-        for (int i = 0; i < NQ; i++) e[i] = (i == j) ? 1.0 : 0.0;
-        rnea_world<NQ, double>(J, g0, q, zero, e, col);
-#pragma unroll
-        for (int i = 0; i < NQ; i++) M[i][j] = col[i];
+    for (int i = 0; i < NQ; i++) {
+        q[i] = xb[i];
+        qd[i] = dyn ? xb[NQ + i] : 0.0;
+        qdd[i] = role == 0 ? u[(size_t)bb * NQ + i] : (role - 2 == i ? 1.0 : 0.0);
     }
+    const double g[3] = {dyn ? D->gravity[0] : 0.0, dyn ? D->gravity[1] : 0.0, dyn ? D->gravity[2] : 0.0};
+    rnea_world<NQ, double>(J, g, q, qd, qdd, out);
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NQ; i++) sm[li][role][i] = out[i];
+    }
+    __syncthreads();
+    if (!live || role != 0) return;
     double rhs[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
-        double t = tau[i] + (tau_noise ? tau_noise[(size_t)b * NQ + i] : 0.0);
+        double t = sm[li][0][i] + (tau_noise ? tau_noise[(size_t)b * NQ + i] : 0.0);
         const double tm = J[i].tau_max;
         t = fmin(fmax(t, -tm), tm);
-        rhs[i] = t - h[i];
+        rhs[i] = t - sm[li][1][i];
     }
-    // M is symmetric positive definite: Cholesky solve
+    // M is symmetric positive definite (column j of M sits in sm[li][2 + j]): Cholesky solve
     double L[NQ][NQ];
 #pragma unroll
     for (int j = 0; j < NQ; j++) {
-        double d = M[j][j];
+        double d = sm[li][2 + j][j];
 #pragma unroll
         for (int t = 0; t < j; t++) d = fma(-L[j][t], L[j][t], d);
         const double lj = sqrt(d);
         L[j][j] = lj;
 #pragma unroll
         for (int i = j + 1; i < NQ; i++) {
-            double v = 0.5 * (M[i][j] + M[j][i]);
+            double v = 0.5 * (sm[li][2 + j][i] + sm[li][2 + i][j]);
 #pragma unroll
             for (int t = 0; t < j; t++) v = fma(-L[i][t], L[j][t], v);
             L[i][j] = v / lj;
