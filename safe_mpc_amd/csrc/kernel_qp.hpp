@@ -22,8 +22,8 @@
 //     last use in this one;
 //   * what many lanes read -- the general rows (a row per constraint lane, a column per variable lane), the factor block,
 //     the B1 image -- arrives as whole 16-byte pieces (every lane useful: a narrow per-lane global load costs the address
-//     unit a full 64-lane instruction) and is laid out in LDS, double-buffered and committed a stage early in the
-//     forward sweeps, over the buffers that only B1 uses;
+//     unit a full 64-lane instruction) and is laid out in LDS over the buffers that only B1 uses (the factor block
+//     double-buffered and committed a stage early in the forward sweeps, so the control chain starts without a hand-off);
 //   * LDS otherwise holds the vectors of the recursions (x, u, costate, row coefficients) and B1's matrices (transposed
 //     Jacobian image, scaled copy, P ping-pong, Lambda, G, W^T); cross-lane hand-offs are wave-scope LDS fences (no
 //     s_barrier, no vmcnt drain);
@@ -528,10 +528,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sWT = sIMG + O_WT;
     double* const sHXX = sIMG + O_HXX;
     static_assert(CST_MAX + 2 * NQ * KS <= O_PVA - O_TD, "staging area of the forward sweeps");
-    // forward sweeps only: [factor block x2 | general rows (x2 when they fit: committed a stage early like the factors)]
-    constexpr bool C_DB = 2 * CST_MAX + 2 * NQ * KS <= O_PVA - O_TD;
-    constexpr int O_WST = O_TD, O_CST = O_TD + 2 * NQ * KS;
-    double* const sWstA = sIMG + O_WST;                    // (B2 stages its factor block here too)
+    double* const sCst = sIMG + O_TD;                      // forward sweeps only: general rows ...
+    double* const sWstA = sIMG + O_TD + CST_MAX;           // ... and the factor block, double-buffered (B2: single)
     double* const sPB = sIMG + O_PB;
     double* const sZU = sIMG + O_ZU;
     double* const sRho = sIMG + O_RHO;
@@ -886,8 +884,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             // (ping-pong buffers as offsets, not pointers: an offset can go through an optimisation barrier without the LDS
             //  address space being lost)
             int o_xb = O_XB, o_xn = O_XB + NX;
-            int o_wc = O_WST, o_wn = O_WST + NQ * KS;    // factor block of this stage / of the next one
-            int o_cc = O_CST, o_cn = C_DB ? O_CST + CST_MAX : O_CST;    // general rows, same
+            int o_wc = O_TD + CST_MAX, o_wn = O_TD + CST_MAX + NQ * KS;    // factor block of this stage / of the next one
             dbl2 Cs[CST_PF], Ws[WST_PF], r0, r1, r2, r3;
             double bi, wsoft;
             auto load_w = [&](int k) {
@@ -899,11 +896,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 dbl2* d2 = reinterpret_cast<dbl2*>(dst);
 #pragma unroll
                 for (int j = 0; j < WST_PF; j++) d2[min(hl + 32 * j, W_N2 - 1)] = Ws[j];
-            };
-            auto commit_c = [&](double* dst) {
-                dbl2* d2 = reinterpret_cast<dbl2*>(dst);
-#pragma unroll
-                for (int j = 0; j < CST_PF; j++) d2[min(hl + 32 * j, c_n2 - 1)] = Cs[j];
             };
             auto load_c = [&](int k) {
                 const double* w = stage_ptr(k);
@@ -926,15 +918,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             load_r(0);
             commit_w(sIMG + o_wc);
             load_w(N > 1 ? 1 : 0);
-            if (C_DB) {
-                commit_c(sIMG + o_cc);
-                load_c(N >= 1 ? 1 : 0);
-            }
             lds_fence();
             // Everything in flight lands before the loop starts (stage 0 needs it at once anyway).  Without this, a register
             // that is still "pending" on loop entry -- a spill reload in the preheader is enough -- makes the compiler put
             // its wait INSIDE the loop body, where it then drains the prefetch queue on every stage.
-            asm volatile("" : "+v"(o_wc), "+v"(o_wn), "+v"(o_xb), "+v"(o_xn), "+v"(o_cc), "+v"(o_cn));   // (reloaded here, not in the preheader)
+            asm volatile("" : "+v"(o_wc), "+v"(o_wn), "+v"(o_xb), "+v"(o_xn));   // (reloaded here, not in the preheader)
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 #pragma unroll 1
             for (int k = 0; k <= N; k++) {
@@ -942,15 +930,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 const bool last = (k == N);
                 const int kn = k < N ? k + 1 : N;          // past the end the loads repeat the end stage: they stay unconditional
                 const int kk = k + 2 < N ? k + 2 : N - 1;  // (there are no factors at the end stage)
-                const int kc = k + 2 < N ? k + 2 : N;
                 double* w = stage_ptr(k);
                 double *const xb = sIMG + o_xb, *const xn = sIMG + o_xn, *const wc_ = sIMG + o_wc, *const wn_ = sIMG + o_wn;
-                double *const sCst = sIMG + o_cc;
-                if (!C_DB) {
-                    // single buffer: general rows -> LDS now (rows for the constraint lanes, columns for a1 / a2)
-                    commit_c(sCst);
-                    load_c(kn);
+                // general rows -> LDS (rows for the constraint lanes, columns for a1 / a2)
+                {
+                    dbl2* d2 = reinterpret_cast<dbl2*>(sCst);
+#pragma unroll
+                    for (int j = 0; j < CST_PF; j++) d2[min(hl + 32 * j, c_n2 - 1)] = Cs[j];
                 }
+                load_c(kn);
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
                     const double* wr_ = wc_ + hl_u * KS;
@@ -1004,13 +992,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     S2 += row_live ? s2_ : 0.0;
                     load_r(kn);
                 }
-                // next stage's factor block (and general rows) -> their LDS buffers; the ones after that -> registers
+                // next stage's factor block -> its LDS buffer; the one after that -> registers
                 commit_w(wn_);
                 load_w(kk);
-                if (C_DB) {
-                    commit_c(sIMG + o_cn);
-                    load_c(kc);
-                }
                 lds_fence();
                 if (!CORR) {
                     double a1 = 0.0, a2 = 0.0;
@@ -1024,11 +1008,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
                     w[Ly.oA1 + hz] = a1;
                     w[Ly.oA2 + hz] = a2;
-                    if (!C_DB) lds_fence();   // (the next stage overwrites the staged rows)
+                    lds_fence();   // (the next stage overwrites the staged rows)
                 }
                 { const int t = o_xb; o_xb = o_xn; o_xn = t; }
                 { const int t = o_wc; o_wc = o_wn; o_wn = t; }
-                if (C_DB) { const int t = o_cc; o_cc = o_cn; o_cn = t; }
                 QPT(CORR ? 11 : 7);
                 if (CORR) asm volatile("; QPMARK F2_END"); else asm volatile("; QPMARK F1_END");
             }
