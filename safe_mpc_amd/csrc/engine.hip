@@ -258,19 +258,22 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         order = h->d_order;
     }
     const int pairs = (int)(((long)B * (h->N + 1) + 1) / 2);
-    if (h->desc.n_rows == 6) {
-        hipLaunchKernelGGL((k_qp_setup<NQ, 6>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,
-                           h->d_ev, h->d_ws, bstride);
-        if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));
-        hipLaunchKernelGGL((k_qp_ipm<NQ, 6>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
-                           xo, uo, st, it, order, h->d_last_it);
-    } else {
-        hipLaunchKernelGGL((k_qp_setup<NQ, -1>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi,
-                           h->d_ev, h->d_ws, bstride);
-        if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));
-        hipLaunchKernelGGL((k_qp_ipm<NQ, -1>), dim3((B + 1) / 2), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, h->d_ws,
-                           xo, uo, st, it, order, h->d_last_it);
+    // the row counts of the shipped geometries are compile-time constants of the kernels (6: the reference's six capsule
+    // pairs, config.yaml:205-216; 4: config_fr7.yaml); any other count takes the runtime-row-count instantiation
+#define SMPC_QP_LAUNCH(MR_)                                                                                                        \
+    do {                                                                                                                           \
+        hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
+                           bhi, h->d_ev, h->d_ws, bstride);                                                                        \
+        if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                           \
+        hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
+                           ug, h->d_ws, xo, uo, st, it, order, h->d_last_it);                                                      \
+    } while (0)
+    switch (h->desc.n_rows) {
+    case 6: SMPC_QP_LAUNCH(6); break;
+    case 4: SMPC_QP_LAUNCH(4); break;
+    default: SMPC_QP_LAUNCH(-1); break;
     }
+#undef SMPC_QP_LAUNCH
     h->order_B = B;
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream));
