@@ -250,3 +250,21 @@ def test_kernel_instantiations_and_odd_batches(nq, B, drop_rows):
     assert np.abs(ia[ok] - ib[ok]).max() <= 2
     assert np.abs(ua[ok] - ub[ok]).max() < 1e-4 * (1 + np.abs(ub[ok]).max())
     assert np.abs(xa[ok] - xb[ok]).max() < 1e-4
+
+
+@pytest.mark.parametrize('N', [1, 2, 3, 63])
+def test_horizon_extremes(N):
+    """Shortest horizons (the unrolled / look-ahead loops of the QP kernel degenerate) and SMPC_MAX_N."""
+    par, prob, net = make_problem('st', 'ext', N=N)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    B = 10
+    x0 = sample_instances(prob, B, seed=7, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    xa, ua, sa, ia = s.solve(x0, xg, ug, p)
+    xb, ub, sb, ib = o.solve_batch(x0, xg, ug, p)
+    assert np.array_equal(sa, sb)
+    ok = sb == 0
+    assert ok.sum() >= B - 1
+    assert np.abs(ia[ok] - ib[ok]).max() <= 2
+    assert np.abs(ua[ok] - ub[ok]).max() < 1e-4 * (1 + np.abs(ub[ok]).max())
+    assert np.abs(xa[ok] - xb[ok]).max() < 1e-4
