@@ -132,6 +132,13 @@ class BatchedOcpSolver:
         """One SQP-RTI solve per instance (controller.py:136-167).  Returns (x, u, status, qp_iter)."""
         B = x0.shape[0]
         N, nx, nu = self.N, self.nx, self.nu
+        if B == 0:      # an empty batch is a loop over no instances (scripts/mpc.py:102), not an error
+            if _is_torch(x0):
+                import torch
+                kw = dict(device=x0.device)
+                return (torch.empty((0, N + 1, nx), dtype=torch.float64, **kw), torch.empty((0, N, nu), dtype=torch.float64, **kw),
+                        torch.empty((0,), dtype=torch.int32, **kw), torch.empty((0,), dtype=torch.int32, **kw))
+            return np.empty((0, N + 1, nx)), np.empty((0, N, nu)), np.empty(0, np.int32), np.empty(0, np.int32)
         shapes = [(B, nx), (B, N + 1, nx), (B, N, nu), (B, N + 1, 5)]
         ptrs, dev, keep = self._prep([x0, x_guess, u_guess, p], shapes)
         if dev:

@@ -268,3 +268,10 @@ def test_horizon_extremes(N):
     assert np.abs(ia[ok] - ib[ok]).max() <= 2
     assert np.abs(ua[ok] - ub[ok]).max() < 1e-4 * (1 + np.abs(ub[ok]).max())
     assert np.abs(xa[ok] - xb[ok]).max() < 1e-4
+
+
+def test_empty_batch_is_a_no_op():
+    par, prob, net = make_problem('naive', N=5)
+    s = _solver(prob, net)
+    x, u, st, it = s.solve(np.zeros((0, 12)), np.zeros((0, 6, 12)), np.zeros((0, 5, 6)), np.zeros((0, 6, 5)))
+    assert x.shape == (0, 6, 12) and u.shape == (0, 5, 6) and st.shape == (0,) and it.shape == (0,)
