@@ -275,3 +275,27 @@ def test_empty_batch_is_a_no_op():
     s = _solver(prob, net)
     x, u, st, it = s.solve(np.zeros((0, 12)), np.zeros((0, 6, 12)), np.zeros((0, 5, 6)), np.zeros((0, 6, 5)))
     assert x.shape == (0, 6, 12) and u.shape == (0, 5, 6) and st.shape == (0,) and it.shape == (0,)
+
+
+@pytest.mark.parametrize('controller', ['st', 'constraint_everywhere'])
+def test_closed_loop_tracks_oracle(controller):
+    """Eight closed-loop RTI steps (guessCorrection -> solve -> provideControl -> plant) on the engine and on the oracle from the
+    same start: same statuses every step, states within 1e-5 at the end (the fp32 network is the only non-FP64 piece)."""
+    par, prob, net = make_problem(controller, 'ext', N=20)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    B = 48
+    x0 = sample_instances(prob, B, seed=11, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    xa, xga, uga = x0.copy(), xg.copy(), ug.copy()
+    xb, xgb, ugb = x0.copy(), xg.copy(), ug.copy()
+    for step in range(8):
+        ra, rb = s.solve(xa, xga, uga, p), o.solve_batch(xb, xgb, ugb, p)
+        assert np.array_equal(ra[2], rb[2]), step
+        acc = (rb[2] == 0).astype(np.int32)
+        xga, uga, ua = s.provide_control(acc, ra[0], ra[1], xga, uga)
+        xgb, ugb, ub = o.provide_control(acc, rb[0], rb[1], xgb, ugb)
+        xa, _ = s.plant_step(xa, ua)
+        xb, _ = o.plant_step(xb, ub)
+        xga, xgb = s.guess_correction(xga, uga), o.guess_correction(xgb, ugb)
+    assert np.abs(xa - xb).max() < 1e-5
+    assert np.abs(xga - xgb).max() < 1e-4
