@@ -224,6 +224,16 @@ int smpc_check_trajectory(smpc_handle* h, int B, int n_nodes, const double* x, c
 int smpc_plant_step(smpc_handle* h, int B, const double* x, const double* u, const smpc_joint* joints_noisy,
                     const double* tau_noise, double* x_next, double* u_eff, int on_device);
 
+/* Closed-loop rollout of the plain RTI policy for n_steps, without a host round trip per step: NaiveController.step
+ * (controller.py:274-284: guessCorrection, solve, fails = status == 0 ? 0 : fails + 1, provideControl(fails == 0)) followed
+ * by the plant step of scripts/mpc.py:151,240 (smpc_plant_step semantics, optional per-instance model and per-step torque
+ * noise).  x_guess / u_guess are the warm start on entry and the shifted guess of the last step on return.
+ * Trajectories are STEP-major: x_traj[n_steps+1][B][nx] (x_traj[0] = x0), u_traj[n_steps][B][nu], status_traj[n_steps][B],
+ * iter_traj[n_steps][B] (may be NULL), tau_noise[n_steps][B][nq] or NULL, joints_noisy[B][nq] or NULL. */
+int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, double* x_guess, double* u_guess,
+                       const double* p, const smpc_joint* joints_noisy, const double* tau_noise, double* x_traj,
+                       double* u_traj, int32_t* status_traj, int32_t* iter_traj, int on_device);
+
 /* wait for the handle's stream */
 int smpc_sync(smpc_handle* h);
 /* the hipStream_t the handle enqueues on (for event timing by the caller) */

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get('SMPC_HIP_LIB') or os.path.join(_CSRC, 'libsmpc_hip.so
 
 SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error', 'smpc_set_mlp', 'smpc_set_horizon',
            'smpc_set_stage_bounds', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',
-           'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_sync', 'smpc_stream',
+           'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_rollout_batch', 'smpc_sync', 'smpc_stream',
            'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing']
 
 
@@ -62,6 +62,7 @@ def lib():
     L.smpc_check_trajectory.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_double, dp, dp, C.c_double, C.c_double,
                                         dp, dp, C.c_int]
     L.smpc_plant_step.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, C.c_int]
+    L.smpc_rollout_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp, C.c_int]
     L.smpc_sync.argtypes = [vp]
     L.smpc_stream.argtypes = [vp]
     L.smpc_stream.restype = C.c_void_p

@@ -58,6 +58,8 @@ struct smpc_handle {
     // timing
     int timing = 0;
     hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t* d_pol = nullptr;   // fails / accept counters of smpc_rollout_batch, [2][pol_B]
+    int pol_B = 0;
     float last_ms[4] = {0, 0, 0, 0};
     char err[256] = "";
 };
@@ -360,6 +362,7 @@ void smpc_destroy(smpc_handle* h) {
         if (h->d_dg[l]) (void)hipFree(h->d_dg[l]);
     }
     for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
+    if (h->d_pol) (void)hipFree(h->d_pol);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -657,6 +660,100 @@ int smpc_plant_step(smpc_handle* h, int B, const double* x, const double* u, con
         HIPCHK(h, hipStreamSynchronize(s));
     }
     return SMPC_OK;
+}
+
+int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, double* x_guess, double* u_guess,
+                       const double* p, const smpc_joint* joints_noisy, const double* tau_noise, double* x_traj,
+                       double* u_traj, int32_t* status_traj, int32_t* iter_traj, int on_device) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || n_steps <= 0 || !x0 || !x_guess || !u_guess || !p || !x_traj || !u_traj || !status_traj)
+        return fail(h, SMPC_EINVAL, "bad argument");
+    (void)hipSetDevice(h->device);
+    const int N = h->N, nq = h->desc.nq, nx = 2 * nq;
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    if ((rc = ensure_io(h, B))) return rc;          // h->d_xo / d_uo receive each step's iterate
+    const size_t nX = (size_t)B * (N + 1) * nx, nU = (size_t)B * N * nq, nP = (size_t)B * (N + 1) * SMPC_NP;
+    const size_t sx = (size_t)B * nx, su = (size_t)B * nq;
+    // device views of the arguments (host pointers: one staging allocation for the call)
+    char* stage = nullptr;
+    const double *dx0 = x0, *dp = p, *dnoise = tau_noise;
+    const smpc_joint* dj = joints_noisy;
+    double *dxg = x_guess, *dug = u_guess, *dxt = x_traj, *dut = u_traj;
+    int32_t *dst = status_traj, *dit = iter_traj;
+    size_t o_x0 = 0, o_xg, o_ug, o_p, o_xt, o_ut, o_j, o_n, o_st, o_it, o_end;
+    if (!on_device) {
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        o_xg = al(o_x0 + sizeof(double) * sx);
+        o_ug = al(o_xg + sizeof(double) * nX);
+        o_p = al(o_ug + sizeof(double) * nU);
+        o_xt = al(o_p + sizeof(double) * nP);
+        o_ut = al(o_xt + sizeof(double) * sx * (n_steps + 1));
+        o_j = al(o_ut + sizeof(double) * su * n_steps);
+        o_n = al(o_j + (joints_noisy ? sizeof(smpc_joint) * (size_t)B * nq : 0));
+        o_st = al(o_n + (tau_noise ? sizeof(double) * su * n_steps : 0));
+        o_it = al(o_st + sizeof(int32_t) * (size_t)B * n_steps);
+        o_end = al(o_it + sizeof(int32_t) * (size_t)B * n_steps);
+        if (hipMalloc((void**)&stage, o_end) != hipSuccess) return fail(h, SMPC_ENOMEM, "hipMalloc(%zu) failed", o_end);
+        dxg = (double*)(stage + o_xg); dug = (double*)(stage + o_ug); dxt = (double*)(stage + o_xt); dut = (double*)(stage + o_ut);
+        dst = (int32_t*)(stage + o_st); dit = (int32_t*)(stage + o_it);
+        hipError_t e = hipMemcpyAsync(stage + o_x0, x0, sizeof(double) * sx, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(dxg, x_guess, sizeof(double) * nX, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(dug, u_guess, sizeof(double) * nU, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(stage + o_p, p, sizeof(double) * nP, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && joints_noisy)
+            e = hipMemcpyAsync(stage + o_j, joints_noisy, sizeof(smpc_joint) * (size_t)B * nq, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess && tau_noise)
+            e = hipMemcpyAsync(stage + o_n, tau_noise, sizeof(double) * su * n_steps, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) { (void)hipFree(stage); return fail(h, SMPC_EHIP, "staging copy failed: %s", hipGetErrorString(e)); }
+        dx0 = (const double*)(stage + o_x0); dp = (const double*)(stage + o_p);
+        dj = joints_noisy ? (const smpc_joint*)(stage + o_j) : nullptr;
+        dnoise = tau_noise ? (const double*)(stage + o_n) : nullptr;
+    } else if (!dit) {
+        dit = h->d_it;
+    }
+    // fails / accept counters of the policy (kept in the handle: the device path returns without synchronising)
+    if (h->pol_B < B) {
+        (void)hipStreamSynchronize(s);
+        if (h->d_pol) (void)hipFree(h->d_pol);
+        h->d_pol = nullptr;
+        h->pol_B = 0;
+        if (hipMalloc((void**)&h->d_pol, sizeof(int32_t) * 2 * (size_t)B) != hipSuccess) {
+            if (stage) (void)hipFree(stage);
+            return fail(h, SMPC_ENOMEM, "hipMalloc failed");
+        }
+        h->pol_B = B;
+    }
+    int32_t *d_fails = h->d_pol, *d_accept = h->d_pol + B;
+    rc = SMPC_OK;
+    hipError_t e = hipMemsetAsync(d_fails, 0, sizeof(int32_t) * B, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dxt, dx0, sizeof(double) * sx, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) rc = fail(h, SMPC_EHIP, "rollout init failed: %s", hipGetErrorString(e));
+    for (int t = 0; t < n_steps && rc == SMPC_OK; t++) {
+        double* xt = dxt + (size_t)t * sx;
+        double* ut = dut + (size_t)t * su;
+        int32_t* itp = (on_device && !iter_traj) ? h->d_it : dit + (size_t)t * B;
+        if ((rc = smpc_guess_correction(h, B, dxg, dug, 1))) break;
+        if ((rc = smpc_solve_batch(h, B, xt, dxg, dug, dp, h->d_xo, h->d_uo, dst + (size_t)t * B, itp, 1))) break;
+        hipLaunchKernelGGL(k_accept, dim3((B + 255) / 256), dim3(256), 0, s, B, dst + (size_t)t * B, d_fails, d_accept);
+        if ((rc = smpc_provide_control(h, B, d_accept, h->d_xo, h->d_uo, dxg, dug, ut, 1))) break;
+        rc = smpc_plant_step(h, B, xt, ut, dj, dnoise ? dnoise + (size_t)t * su : nullptr, xt + sx, nullptr, 1);
+    }
+    if (rc == SMPC_OK && !on_device) {
+        e = hipMemcpyAsync(x_traj, dxt, sizeof(double) * sx * (n_steps + 1), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(u_traj, dut, sizeof(double) * su * n_steps, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(status_traj, dst, sizeof(int32_t) * (size_t)B * n_steps, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && iter_traj) e = hipMemcpyAsync(iter_traj, dit, sizeof(int32_t) * (size_t)B * n_steps, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(x_guess, dxg, sizeof(double) * nX, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(u_guess, dug, sizeof(double) * nU, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) rc = fail(h, SMPC_EHIP, "copy back failed: %s", hipGetErrorString(e));
+    }
+    if (stage) {   // host path: results are on the host when the call returns
+        if (hipStreamSynchronize(s) != hipSuccess && rc == SMPC_OK) rc = fail(h, SMPC_EHIP, "stream synchronisation failed");
+        (void)hipFree(stage);
+    }
+    return rc;
 }
 
 int smpc_sync(smpc_handle* h) {

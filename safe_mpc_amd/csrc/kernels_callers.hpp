@@ -126,6 +126,15 @@ __global__ void k_check_nn(const smpc_problem_desc* __restrict__ D, int M, const
     nn_ok[m] = (g >= -tol_safe) && (g <= 1e6 + tol_safe);
 }
 
+// NaiveController.step's bookkeeping (controller.py:279-283): fails = status == 0 ? 0 : fails + 1; accept = fails == 0
+__global__ void k_accept(int B, const int32_t* __restrict__ status, int32_t* __restrict__ fails, int32_t* __restrict__ accept) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int f = status[b] == 0 ? 0 : fails[b] + 1;
+    fails[b] = f;
+    accept[b] = f == 0;
+}
+
 // plant step AdamModel.integrate (env_model.py:192-206).  NQ + 2 lanes per instance, one inverse-dynamics call each: lane 0
 // tau(q, qd, u), lane 1 the bias h(q, qd), lanes 2.. the columns of M (unit accelerations, no velocity, no gravity) -- the
 // same code with different inputs, so the wavefront does not diverge; lane 0 then solves M a = clamp(tau + noise) - h.

@@ -226,6 +226,47 @@ class BatchedOcpSolver:
                                                alpha, tol_safe, ok.ctypes.data, nn.ctypes.data if want_nn else None, 0))
         return (ok.astype(bool), nn.astype(bool)) if want_nn else ok.astype(bool)
 
+    def rollout(self, x0, x_guess, u_guess, p, n_steps, joints_noisy=None, tau_noise=None):
+        """n_steps of the plain RTI policy + plant without a host round trip per step (smpc_rollout_batch).
+        x_guess / u_guess are updated in place (torch) or returned updated (numpy).  Returns step-major
+        (x_traj[n+1, B, nx], u_traj[n, B, nu], status[n, B], qp_iter[n, B], x_guess, u_guess)."""
+        B, n = x0.shape[0], int(n_steps)
+        N, nx, nu = self.N, self.nx, self.nu
+        if _is_torch(x0):
+            import torch
+            kw = dict(device=x0.device)
+            xt = torch.empty((n + 1, B, nx), dtype=torch.float64, **kw)
+            ut = torch.empty((n, B, nu), dtype=torch.float64, **kw)
+            st = torch.empty((n, B), dtype=torch.int32, **kw)
+            it = torch.empty((n, B), dtype=torch.int32, **kw)
+            jn = joints_noisy.data_ptr() if joints_noisy is not None else None
+            tn = tau_noise.data_ptr() if tau_noise is not None else None
+            for a, shp in ((x0, (B, nx)), (x_guess, (B, N + 1, nx)), (u_guess, (B, N, nu)), (p, (B, N + 1, 5))):
+                if tuple(a.shape) != shp or a.dtype != torch.float64 or not a.is_contiguous():
+                    raise ValueError(f'rollout: expected a contiguous float64 tensor of shape {shp}')
+            self._chk(self.L.smpc_rollout_batch(self.h, B, n, x0.data_ptr(), x_guess.data_ptr(), u_guess.data_ptr(), p.data_ptr(),
+                                                jn, tn, xt.data_ptr(), ut.data_ptr(), st.data_ptr(), it.data_ptr(), 1))
+            return xt, ut, st, it, x_guess, u_guess
+        x0 = np.ascontiguousarray(x0, np.float64)
+        xg = np.array(x_guess, np.float64, order='C', copy=True)
+        ug = np.array(u_guess, np.float64, order='C', copy=True)
+        pp = np.ascontiguousarray(p, np.float64)
+        assert x0.shape == (B, nx) and xg.shape == (B, N + 1, nx) and ug.shape == (B, N, nu) and pp.shape == (B, N + 1, 5)
+        xt, ut = np.empty((n + 1, B, nx)), np.empty((n, B, nu))
+        st, it = np.empty((n, B), np.int32), np.empty((n, B), np.int32)
+        jn = tn = None
+        if joints_noisy is not None:
+            joints_noisy = np.ascontiguousarray(joints_noisy, JOINT_DTYPE)
+            assert joints_noisy.shape == (B, self.nq)
+            jn = joints_noisy.ctypes.data
+        if tau_noise is not None:
+            tau_noise = np.ascontiguousarray(tau_noise, np.float64)
+            assert tau_noise.shape == (n, B, nu)
+            tn = tau_noise.ctypes.data
+        self._chk(self.L.smpc_rollout_batch(self.h, B, n, x0.ctypes.data, xg.ctypes.data, ug.ctypes.data, pp.ctypes.data, jn, tn,
+                                            xt.ctypes.data, ut.ctypes.data, st.ctypes.data, it.ctypes.data, 0))
+        return xt, ut, st, it, xg, ug
+
     def plant_step(self, x, u, joints_noisy=None, tau_noise=None):
         """AdamModel.integrate (env_model.py:192-206) for B instances."""
         B = x.shape[0]

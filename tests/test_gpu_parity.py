@@ -299,3 +299,39 @@ def test_closed_loop_tracks_oracle(controller):
         xga, xgb = s.guess_correction(xga, uga), o.guess_correction(xgb, ugb)
     assert np.abs(xa - xb).max() < 1e-5
     assert np.abs(xga - xgb).max() < 1e-4
+
+
+def test_rollout_equals_step_by_step():
+    """smpc_rollout_batch is the same launch sequence as the step-by-step calls: bitwise equal trajectories, host and
+    device pointer paths, with per-step torque noise."""
+    import torch
+    par, prob, net = make_problem('st', 'ext', N=15)
+    s = _solver(prob, net)
+    B, n = 33, 6
+    x0 = sample_instances(prob, B, seed=13, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    noise = 0.05 * np.random.default_rng(3).standard_normal((n, B, 6))
+    # step by step (host path)
+    x, xg1, ug1, fails = x0.copy(), xg.copy(), ug.copy(), np.zeros(B, np.int64)
+    X, U, S = [x0.copy()], [], []
+    for t in range(n):
+        xg1 = s.guess_correction(xg1, ug1)
+        xo, uo, st, it = s.solve(x, xg1, ug1, p)
+        fails = np.where(st == 0, 0, fails + 1)
+        xg1, ug1, ua = s.provide_control((fails == 0).astype(np.int32), xo, uo, xg1, ug1)
+        x, _ = s.plant_step(x, ua, tau_noise=noise[t])
+        X.append(x.copy()); U.append(ua.copy()); S.append(st.copy())
+    X, U, S = np.array(X), np.array(U), np.array(S)
+    # one call, host pointers
+    xt, ut, st_, it_, xg2, ug2 = s.rollout(x0, xg, ug, p, n, tau_noise=noise)
+    assert np.array_equal(st_, S) and np.array_equal(xt, X) and np.array_equal(ut, U)
+    assert np.array_equal(xg2, xg1) and np.array_equal(ug2, ug1)
+    assert (it_ > 0).all()
+    # one call, device pointers
+    dev = torch.device('cuda:0')
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    xgd, ugd = t(xg), t(ug)
+    xtd, utd, std, itd, _, _ = s.rollout(t(x0), xgd, ugd, t(p), n, tau_noise=t(noise))
+    s.sync()
+    assert np.array_equal(xtd.cpu().numpy(), X) and np.array_equal(utd.cpu().numpy(), U) and np.array_equal(std.cpu().numpy(), S)
+    assert np.array_equal(xgd.cpu().numpy(), xg1)
