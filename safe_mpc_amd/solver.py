@@ -161,7 +161,17 @@ class BatchedOcpSolver:
         N, nx, nu = self.N, self.nx, self.nu
         ptrs, dev, keep = self._prep([x_guess, u_guess, p], [(B, N + 1, nx), (B, N, nu), (B, N + 1, 5)])
         if dev:
-            raise NotImplementedError('eval_nodes is a host-path diagnostic')
+            # device path: a dict of float64 views into one [B, N+1, sizeof(smpc_node_eval)/8] tensor, same field names
+            import torch
+            nd = NODE_EVAL_DTYPE.itemsize // 8
+            raw = torch.zeros((B, N + 1, nd), dtype=torch.float64, device=x_guess.device)
+            self._chk(self.L.smpc_eval_nodes(self.h, B, *ptrs, raw.data_ptr(), 1))
+            out = {}
+            for name in NODE_EVAL_DTYPE.names:
+                dt, off = NODE_EVAL_DTYPE.fields[name][:2]
+                n = dt.itemsize // 8
+                out[name] = raw[..., off // 8: off // 8 + n] if dt.shape else raw[..., off // 8]
+            return out
         out = np.zeros((B, N + 1), NODE_EVAL_DTYPE)
         self._chk(self.L.smpc_eval_nodes(self.h, B, *ptrs, out.ctypes.data, 0))
         return out

@@ -335,3 +335,20 @@ def test_rollout_equals_step_by_step():
     s.sync()
     assert np.array_equal(xtd.cpu().numpy(), X) and np.array_equal(utd.cpu().numpy(), U) and np.array_equal(std.cpu().numpy(), S)
     assert np.array_equal(xgd.cpu().numpy(), xg1)
+
+
+def test_eval_nodes_device_path_matches_host_path():
+    import torch
+    par, prob, net = make_problem('st', 'ext', N=8)
+    s = _solver(prob, net)
+    B = 9
+    x0 = sample_instances(prob, B, seed=4, vel_scale=0.2)
+    xg, ug, p = constant_guess(prob, x0)
+    ug += 1.0
+    a = s.eval_nodes(xg, ug, p)
+    dev = torch.device('cuda:0')
+    t = lambda v: torch.tensor(v, dtype=torch.float64, device=dev)
+    b = s.eval_nodes(t(xg), t(ug), t(p))
+    s.sync()
+    for f in ('tau', 'M', 'dtau_dq', 'dtau_dv', 'ee', 'cost_grad_q', 'cost_hess_qq', 'row_val', 'row_grad', 'nn_val', 'nn_grad'):
+        assert np.array_equal(np.asarray(a[f]), b[f].cpu().numpy()), f
