@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU = 4096
 HORIZON = 30
-CONTROLLER = 'st'
+CONTROLLER = os.environ.get('SMPC_BENCH_CONTROLLER', 'st')   # 'constraint_everywhere': the safe-set row on ALL nodes (reported separately)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -305,7 +305,8 @@ def main():
             'value': total / elapsed, 'unit': 'instance-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'C1: Z1-class 6-DoF, N=30, 4096 instances/GPU, controller st (soft terminal NN row, '
+            'config': {'workload': 'C1: Z1-class 6-DoF, N=30, 4096 instances/GPU, controller ' + CONTROLLER +
+                                   (' (soft terminal NN row, ' if CONTROLLER == 'st' else ' (NN row as configured, ') +
                                    'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',
                        'batch_per_gpu': B, 'horizon': N, 'controller': CONTROLLER, 'streams_per_gpu': S, 'hip_graphs': bool(subs[0].graph is not None),
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,

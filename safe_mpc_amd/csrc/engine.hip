@@ -191,16 +191,28 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
     const dim3 blk(256), grd(Mp / 128, H / 64);
     hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, MLP_KPAD, h->d_S, h->d_Wfwd[0], h->d_bias[0],
                        (const float*)nullptr, h->d_act[0], h->d_dg[0]);
-    for (int l = 1; l + 1 < L; l++)
-        hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
-                           h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l]);
+    // hidden x hidden layers: LDS-tiled kernel once there are enough 128 x 128 tiles to fill the chip
+    const bool tiled = Mp >= 8192 && H % 128 == 0;
+    const dim3 grd_t(Mp / 128, H / 128);
+    for (int l = 1; l + 1 < L; l++) {
+        if (tiled)
+            hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_BIAS_GELU>), grd_t, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
+                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l]);
+        else
+            hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
+                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l]);
+    }
     hipLaunchKernelGGL(k_nn_output, dim3((Mp + 3) / 4), blk, 0, s, Mp, H, h->d_act[L - 2], h->d_dg[L - 2],
                        h->d_Wbwd[L - 1], h->d_bias[L - 1], h->d_y, h->d_dA);
     if (backward) {
         float *cur = h->d_dA, *nxt = h->d_dB;
         for (int l = L - 2; l >= 1; l--) {
-            hipLaunchKernelGGL((k_gemm_f32<EPI_MUL>), grd, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l], (const float*)nullptr,
-                               h->d_dg[l - 1], nxt, (float*)nullptr);
+            if (tiled)
+                hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_MUL>), grd_t, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l],
+                                   (const float*)nullptr, h->d_dg[l - 1], nxt, (float*)nullptr);
+            else
+                hipLaunchKernelGGL((k_gemm_f32<EPI_MUL>), grd, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l], (const float*)nullptr,
+                                   h->d_dg[l - 1], nxt, (float*)nullptr);
             float* t = cur; cur = nxt; nxt = t;
         }
         hipLaunchKernelGGL((k_gemm_f32<EPI_PLAIN>), dim3(Mp / 128, MLP_NPAD / 64), blk, 0, s, Mp, MLP_NPAD, H, cur,

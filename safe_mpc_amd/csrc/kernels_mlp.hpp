@@ -107,6 +107,92 @@ __global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const flo
     }
 }
 
+// The same product for large M (the safe-set row on every node: M = B * N rows): a 256-thread block owns a 128 x 128 tile
+// of C, each of its four wavefronts a 64 x 64 quarter (2 x 2 MFMA tiles, 64 accumulator registers); A and B are staged
+// through LDS in k-chunks of 16 (register prefetch of the next chunk while the current one feeds 32 MFMAs per wave), so an
+// operand is read from L2 once per block instead of once per wavefront.  M % 128 == 0, N % 128 == 0, K % 16 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f32_tiled(int M, int N, int K, const float* __restrict__ A,
+                                                        const float* __restrict__ Bm, const float* __restrict__ bias,
+                                                        const float* __restrict__ aux, float* __restrict__ out1,
+                                                        float* __restrict__ out2) {
+    constexpr int TM = 128, TN = 128, TK = 16, AS = TK + 1, BS = TN + 32;   // row strides: conflict-free column / row reads
+    __shared__ float As[2][TM * AS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TK * BS];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+    // global -> register staging: A 128 x 16 = 512 float4 (2 per thread), B 16 x 128 = 512 float4 (2 per thread)
+    const int ar = t >> 2, ac = (t & 3) * 4;          // A: rows ar, ar + 64; columns ac .. ac+3
+    const int bk = t >> 5, bn = (t & 31) * 4;         // B: rows bk, bk + 8;  columns bn .. bn+3
+    const float* ap = A + (size_t)(m0 + ar) * K + ac;
+    const float* bp = Bm + (size_t)bk * N + n0 + bn;
+    f32x4 ra0, ra1, rb0, rb1;
+    auto gload = [&](int k0) {
+        ra0 = *reinterpret_cast<const f32x4*>(ap + k0);
+        ra1 = *reinterpret_cast<const f32x4*>(ap + (size_t)64 * K + k0);
+        rb0 = *reinterpret_cast<const f32x4*>(bp + (size_t)k0 * N);
+        rb1 = *reinterpret_cast<const f32x4*>(bp + (size_t)(k0 + 8) * N);
+    };
+    auto sstore = [&](int buf) {
+        float* a = As[buf] + ar * AS + ac;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { a[c] = ra0[c]; a[64 * AS + c] = ra1[c]; }
+        *reinterpret_cast<f32x4*>(Bs[buf] + bk * BS + bn) = rb0;
+        *reinterpret_cast<f32x4*>(Bs[buf] + (bk + 8) * BS + bn) = rb1;
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += TK) {
+        const bool more = k0 + TK < K;
+        if (more) gload(k0 + TK);
+        const float* a = As[buf] + (wm + li) * AS + lh;
+        const float* b = Bs[buf] + lh * BS + wn + li;
+#pragma unroll
+        for (int s2 = 0; s2 < TK / 2; s2++) {
+            const float a0 = a[2 * s2], a1 = a[32 * AS + 2 * s2];
+            const float b0 = b[2 * s2 * BS], b1 = b[2 * s2 * BS + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const int row = m0 + wm + 32 * i + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                const int col = n0 + wn + 32 * j + li;
+                const float v = acc[i][j][reg];
+                const size_t o = (size_t)row * N + col;
+                if (EPI == EPI_BIAS_GELU) {
+                    float dg;
+                    out1[o] = gelu_tanh_f(v + bias[col], &dg);
+                    out2[o] = dg;
+                } else if (EPI == EPI_MUL) {
+                    out1[o] = v * aux[o];
+                } else {
+                    out1[o] = v;
+                }
+            }
+}
+
 // features of the safe-set network (safe_set.py:82-87): s = [(q - mean)/std ; v/|v|], v = qd with eps on v_0.
 // row m <-> node:  mode 0: node = m (plain list of states);  mode 1 (terminal): node = m (N+1) + N;
 //                  mode 2 (all nodes but the first): b = m / N, k = 1 + m % N.

@@ -352,3 +352,16 @@ def test_eval_nodes_device_path_matches_host_path():
     s.sync()
     for f in ('tau', 'M', 'dtau_dq', 'dtau_dv', 'ee', 'cost_grad_q', 'cost_hess_qq', 'row_val', 'row_grad', 'nn_val', 'nn_grad'):
         assert np.array_equal(np.asarray(a[f]), b[f].cpu().numpy()), f
+
+
+def test_mlp_tiled_gemm_path():
+    """The safe-set row on every node of 512 instances x 16 stages = 8 192 MLP rows takes the LDS-tiled GEMM kernel."""
+    par, prob, net = make_problem('constraint_everywhere', 'ext', N=16)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    B = 512
+    x0 = sample_instances(prob, B, seed=6, vel_scale=0.3)
+    xg, ug, p = constant_guess(prob, x0)
+    xg[:, 1:] += 0.05 * np.random.default_rng(0).standard_normal(xg[:, 1:].shape)
+    a, b = s.eval_nodes(xg, ug, p), o.eval_nodes(xg, ug, p)
+    assert _rel(a['nn_val'], b['nn_val']) < 2e-5
+    assert _rel(a['nn_grad'][..., :12], b['nn_grad'][..., :12]) < 2e-4
