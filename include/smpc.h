@@ -116,10 +116,15 @@ typedef struct {
     int32_t nn_mode;
     int32_t nn_dof;            /* n_dof_safe_set (config.yaml:11) */
     int32_t qp_max_iter;       /* qp_solver_iter_max (config.yaml:18) */
-    int32_t reserved0;
+    int32_t rows_at_node0;     /* != 0: the collision rows are kept at node 0, as the reference does when --noise == 0
+                                * (controller.py:77-79; removed for noisy runs, :69-73).  x_0 is pinned, so they are
+                                * constants of the QP: a violated one makes the QP infeasible and the instance reports
+                                * SMPC_STATUS_QP_FAILURE (the iterate is still returned, as acados does) */
     double dt;                 /* config.yaml:7 */
     double Q, R;               /* config.yaml:35,39 */
-    double cost_scale_stage;   /* acados multiplies stage costs by dt, terminal by 1 [EXT-UNVERIFIED] */
+    double cost_scale_stage;   /* factor on the cost Q|ee-ref|^2 + R|u|^2 whose derivatives smpc_node_eval reports: acados
+                                * multiplies stage costs by dt and the terminal one by 1 [EXT-UNVERIFIED]; a NONLINEAR_LS cost
+                                * is 1/2 |y|^2_W (cost_definition.py:61-81), i.e. a further factor 1/2 on both */
     double cost_scale_term;
     double lm_stage;           /* Levenberg-Marquardt added to every diagonal of the stage Hessian */
     double lm_term;

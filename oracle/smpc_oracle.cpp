@@ -26,8 +26,8 @@
  *
  * Formulation differences from the GPU code are deliberate (they make agreement meaningful): this file uses the
  * classic link-frame Newton-Euler recursion, forward-mode dual numbers for every derivative, dense per-stage
- * matrices and a textbook Riccati recursion; the HIP kernels use world-frame spatial algebra, analytic
- * derivatives and wave-cooperative LDS tiles.
+ * matrices and a textbook Riccati recursion; the HIP kernels use world-frame spatial algebra, closed-form
+ * derivatives of the recursion (no dual numbers) and wave-cooperative LDS tiles.
  */
 #include <algorithm>
 #include <cmath>
@@ -838,12 +838,23 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
 }
 
 /* build the stage QP of one instance from node evaluations */
-void build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const double* hi_st,
+bool build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const double* hi_st,
               const std::vector<smpc_node_eval>& ev, const double* x0, const double* xg, const double* ug,
               const double* p, std::vector<Stage>& S, double* dx0) {
     int nq = D.nq, nx = 2 * nq, nu = nq;
     double dt = D.dt, c = 0.5 * dt * dt;
     for (int i = 0; i < nx; i++) dx0[i] = x0[i] - xg[i];
+    /* collision rows at node 0 (kept by the reference when --noise == 0, controller.py:77-79): x_0 is pinned, so the
+     * linearised rows are constants -- outside their bounds the QP is infeasible (reported as QP failure) */
+    bool infeasible0 = false;
+    if (D.rows_at_node0) {
+        for (int i = 0; i < D.n_rows; i++) {
+            double v = ev[0].row_val[i];
+            for (int j = 0; j < nq; j++) v += ev[0].row_grad[i * nq + j] * dx0[j];
+            if (std::fabs(D.rows[i].lb) < SMPC_INF && v < D.rows[i].lb - D.qp_tol) infeasible0 = true;
+            if (std::fabs(D.rows[i].ub) < SMPC_INF && v > D.rows[i].ub + D.qp_tol) infeasible0 = true;
+        }
+    }
     for (int k = 0; k <= N; k++) {
         Stage& s = S[k];
         const smpc_node_eval& e = ev[k];
@@ -923,6 +934,7 @@ void build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const doub
         }
         s.nr = r;
     }
+    return infeasible0;
 }
 
 struct Oracle {
@@ -1070,13 +1082,14 @@ int orc_solve_batch(void* h, int B, const double* x0, const double* xg, const do
         const size_t boff = (size_t)b * (N + 1) * nx;
         const double* blo = o->inst_B == B ? o->lo_b.data() + boff : o->lo_st.data();
         const double* bhi = o->inst_B == B ? o->hi_b.data() + boff : o->hi_st.data();
-        build_qp(D, N, blo, bhi, ev, x0 + (size_t)b * nx, xb, ub, pb, S, dx0);
+        const bool infeasible0 = build_qp(D, N, blo, bhi, ev, x0 + (size_t)b * nx, xb, ub, pb, S, dx0);
         int it = 0;
         double res[2] = {0, 0};
         int qs = qp_ipm(S, N, nx, nu, D.dt, dx0, qo, &it, res);
         /* full step (FIXED_STEP, parser.py:139).  acados' RTI tolerates a QP that stopped at its iteration cap and
          * reports success [EXT-UNVERIFIED]; breakdown and min-step are ACADOS_QP_FAILURE. */
         int st = (qs == 0 || qs == 2) ? SMPC_STATUS_SUCCESS : SMPC_STATUS_QP_FAILURE;
+        if (infeasible0) st = SMPC_STATUS_QP_FAILURE;
         double* xo = x_out + (size_t)b * (N + 1) * nx;
         double* uo = u_out + (size_t)b * N * nu;
         bool nan = false;

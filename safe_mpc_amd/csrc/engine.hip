@@ -55,8 +55,11 @@ struct smpc_handle {
     // generic scratch for the caller entry points
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
+    char* d_roll = nullptr;     // staging of smpc_rollout_batch's host-pointer path, grown on demand
+    size_t roll_bytes = 0;
     // timing
     int timing = 0;
+    int timed = 0;              // a solve has been timed since timing was enabled
     hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int32_t* d_pol = nullptr;   // fails / accept counters of smpc_rollout_batch, [2][pol_B]
     int pol_B = 0;
@@ -122,7 +125,7 @@ int ensure_batch(smpc_handle* h, int B) {
     if (B > h->capB || need > h->ws_bytes) {
         int rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if ((rc = dev_alloc(h, &h->d_ev, (size_t)B * (SMPC_MAX_N + 1)))) return rc;
+        if ((rc = dev_alloc(h, &h->d_ev, (size_t)B * (h->N + 1)))) return rc;
         if ((rc = dev_alloc(h, &h->d_ws, per * (size_t)B))) return rc;
         if ((rc = dev_alloc(h, &h->d_order, (size_t)B))) return rc;
         if ((rc = dev_alloc(h, &h->d_last_it, (size_t)B))) return rc;
@@ -136,7 +139,7 @@ int ensure_batch(smpc_handle* h, int B) {
 
 int ensure_io(smpc_handle* h, int B) {
     if (B <= h->capIO) return SMPC_OK;
-    const int nx = 2 * h->desc.nq, nu = h->desc.nq, NN = SMPC_MAX_N;
+    const int nx = 2 * h->desc.nq, nu = h->desc.nq, NN = h->N;   // (smpc_set_horizon resets capIO)
     int rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if ((rc = dev_alloc(h, &h->d_x0, (size_t)B * nx))) return rc;
@@ -290,7 +293,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
 #undef SMPC_QP_LAUNCH
     h->order_B = B;
     HIPCHK(h, hipGetLastError());
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream));
+    if (h->timing) { HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream)); h->timed = 1; }
     return SMPC_OK;
 }
 
@@ -375,6 +378,7 @@ void smpc_destroy(smpc_handle* h) {
     }
     for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
     if (h->d_pol) (void)hipFree(h->d_pol);
+    if (h->d_roll) (void)hipFree(h->d_roll);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -424,7 +428,8 @@ int smpc_set_horizon(smpc_handle* h, int N) {
     (void)hipSetDevice(h->device);
     h->N = N;
     h->inst_B = 0;
-    h->ws_bytes = 0;  // workspace layout depends on N
+    h->ws_bytes = 0;  // workspace layout, linearisation records and IO staging are sized by N
+    h->capIO = 0;
     return upload_bounds(h, nullptr, nullptr);
 }
 
@@ -606,9 +611,7 @@ int smpc_check_trajectory(smpc_handle* h, int B, int n_nodes, const double* x, c
         d_ok = (int32_t*)(dx + M * nx);
         d_nn = d_ok + B;
     }
-    std::vector<int32_t> ones(B, 1);
-    HIPCHK(h, hipMemcpyAsync(d_ok, ones.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipStreamSynchronize(s));  // `ones` is a stack-lifetime source
+    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)d_ok, 1, (size_t)B, s));   // verdicts start at "ok", stream-ordered
     switch (nq) {
     case 5: hipLaunchKernelGGL((k_check_nodes<5>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
     case 6: hipLaunchKernelGGL((k_check_nodes<6>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
@@ -707,7 +710,13 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
         o_st = al(o_n + (tau_noise ? sizeof(double) * su * n_steps : 0));
         o_it = al(o_st + sizeof(int32_t) * (size_t)B * n_steps);
         o_end = al(o_it + sizeof(int32_t) * (size_t)B * n_steps);
-        if (hipMalloc((void**)&stage, o_end) != hipSuccess) return fail(h, SMPC_ENOMEM, "hipMalloc(%zu) failed", o_end);
+        if (o_end > h->roll_bytes) {
+            HIPCHK(h, hipStreamSynchronize(s));
+            if (h->d_roll) { (void)hipFree(h->d_roll); h->d_roll = nullptr; h->roll_bytes = 0; }
+            if (hipMalloc((void**)&h->d_roll, o_end) != hipSuccess) return fail(h, SMPC_ENOMEM, "hipMalloc(%zu) failed", o_end);
+            h->roll_bytes = o_end;
+        }
+        stage = h->d_roll;
         dxg = (double*)(stage + o_xg); dug = (double*)(stage + o_ug); dxt = (double*)(stage + o_xt); dut = (double*)(stage + o_ut);
         dst = (int32_t*)(stage + o_st); dit = (int32_t*)(stage + o_it);
         hipError_t e = hipMemcpyAsync(stage + o_x0, x0, sizeof(double) * sx, hipMemcpyHostToDevice, s);
@@ -718,7 +727,7 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
             e = hipMemcpyAsync(stage + o_j, joints_noisy, sizeof(smpc_joint) * (size_t)B * nq, hipMemcpyHostToDevice, s);
         if (e == hipSuccess && tau_noise)
             e = hipMemcpyAsync(stage + o_n, tau_noise, sizeof(double) * su * n_steps, hipMemcpyHostToDevice, s);
-        if (e != hipSuccess) { (void)hipFree(stage); return fail(h, SMPC_EHIP, "staging copy failed: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) return fail(h, SMPC_EHIP, "staging copy failed: %s", hipGetErrorString(e));
         dx0 = (const double*)(stage + o_x0); dp = (const double*)(stage + o_p);
         dj = joints_noisy ? (const smpc_joint*)(stage + o_j) : nullptr;
         dnoise = tau_noise ? (const double*)(stage + o_n) : nullptr;
@@ -731,10 +740,8 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
         if (h->d_pol) (void)hipFree(h->d_pol);
         h->d_pol = nullptr;
         h->pol_B = 0;
-        if (hipMalloc((void**)&h->d_pol, sizeof(int32_t) * 2 * (size_t)B) != hipSuccess) {
-            if (stage) (void)hipFree(stage);
+        if (hipMalloc((void**)&h->d_pol, sizeof(int32_t) * 2 * (size_t)B) != hipSuccess)
             return fail(h, SMPC_ENOMEM, "hipMalloc failed");
-        }
         h->pol_B = B;
     }
     int32_t *d_fails = h->d_pol, *d_accept = h->d_pol + B;
@@ -763,7 +770,6 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
     }
     if (stage) {   // host path: results are on the host when the call returns
         if (hipStreamSynchronize(s) != hipSuccess && rc == SMPC_OK) rc = fail(h, SMPC_EHIP, "stream synchronisation failed");
-        (void)hipFree(stage);
     }
     return rc;
 }
@@ -780,12 +786,14 @@ void* smpc_stream(smpc_handle* h) { return h ? (void*)h->stream : nullptr; }
 int smpc_enable_timing(smpc_handle* h, int on) {
     if (!h) return SMPC_EINVAL;
     h->timing = on ? 1 : 0;
+    h->timed = 0;
     return SMPC_OK;
 }
 
 int smpc_get_timing(smpc_handle* h, float* ms4) {
     if (!h || !ms4) return SMPC_EINVAL;
     if (!h->timing) return fail(h, SMPC_ESTATE, "timing not enabled");
+    if (!h->timed) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
     (void)hipSetDevice(h->device);
     HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
     HIPCHK(h, hipEventElapsedTime(&ms4[0], h->ev_t[0], h->ev_t[1]));
@@ -798,6 +806,7 @@ int smpc_get_timing(smpc_handle* h, float* ms4) {
 int smpc_get_qp_timing(smpc_handle* h, float* ms2) {
     if (!h || !ms2) return SMPC_EINVAL;
     if (!h->timing) return fail(h, SMPC_ESTATE, "timing not enabled");
+    if (!h->timed) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
     (void)hipSetDevice(h->device);
     HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
     HIPCHK(h, hipEventElapsedTime(&ms2[0], h->ev_t[2], h->ev_t[4]));

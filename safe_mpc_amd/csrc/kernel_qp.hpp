@@ -97,7 +97,7 @@ template <int NQ> struct QpLayout {
         oA1 = o; o += NZ;                  // C^T e1, C^T e2: the corrector gradient is gh0 + sigma mu a1 + cw a2 (F1 -> B2)
         oA2 = o; o += NZ;
         oPB = o; o += NX;                  // P b
-        oPART = o; o += 4;                 // setup partials [R0, sum lambda t, count]
+        oPART = o; o += 4;                 // setup partials [R0, sum lambda t, count, node-0 rows infeasible]
         stride = qp_even_c(o);
     }
     __host__ __device__ size_t per_instance(int N) const { return (size_t)stride * (N + 1); }
@@ -455,8 +455,17 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         if (k == 0) ax = hl < NQ ? sZ0[NU + hl] + dt * sZ0[NU + NQ + hl] : sZ0[NU + hl];
         r0_loc = fmax(r0_loc, fabs(ax + sB[hl]));
     }
-    const double R0 = half_max(r0_loc), musum = half_sum(mu_acc), cntsum = half_sum((double)cnt);
-    if (hl < 4) w[Ly.oPART + hl] = hl == 0 ? R0 : (hl == 1 ? musum : (hl == 2 ? cntsum : 0.0));
+    // collision rows at node 0 (kept by the reference when --noise == 0, controller.py:77-79): x_0 is pinned, so the linearised
+    // rows are constants of the QP -- one outside its bounds makes the QP infeasible (the instance reports QP failure)
+    double inf0 = 0.0;
+    if (k == 0 && D->rows_at_node0 && hl >= rC0 && hl < rNN) {
+        const smpc_row& row = D->rows[hl - rC0];
+        double v = e.row_val[hl - rC0];
+        for (int c = 0; c < NZ; c++) v = fma(sC[(hl - NX) * NZP + c], sZ0[c], v);
+        if ((fabs(row.lb) < SMPC_INF && v < row.lb - D->qp_tol) || (fabs(row.ub) < SMPC_INF && v > row.ub + D->qp_tol)) inf0 = 1.0;
+    }
+    const double R0 = half_max(r0_loc), musum = half_sum(mu_acc), cntsum = half_sum((double)cnt), infs = half_max(inf0);
+    if (hl < 4) w[Ly.oPART + hl] = hl == 0 ? R0 : (hl == 1 ? musum : (hl == 2 ? cntsum : infs));
 }
 
 #ifndef QP_WAVES_PER_EU
@@ -611,15 +620,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // ---- initial residual norm and complementarity from the setup partials -----------------------------------------------
     double R0 = 0.0, mu;
     int m_comp;
+    bool infeasible0;
     {
-        double ms = 0.0, cn = 0.0;
+        double ms = 0.0, cn = 0.0, inf0 = 0.0;
         for (int k = hl; k <= N; k += 32) {
             const double* pt = ws + (size_t)k * Ly.stride + Ly.oPART;
             R0 = fmax(R0, pt[0]);
             ms += pt[1];
             cn += pt[2];
+            inf0 = fmax(inf0, pt[3]);
         }
         R0 = half_max(R0);
+        infeasible0 = half_max(inf0) > 0.0;
         m_comp = (int)half_sum(cn);
         if (m_comp == 0) m_comp = 1;
         mu = half_sum(ms) / (double)m_comp;
@@ -1175,6 +1187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     if (hl == 0) {
         // acados' RTI tolerates a QP that stopped at its iteration cap (see oracle); breakdown / min-step are QP failures
         int stc = (st_code == 0 || st_code == 2) ? SMPC_STATUS_SUCCESS : SMPC_STATUS_QP_FAILURE;
+        if (infeasible0) stc = SMPC_STATUS_QP_FAILURE;   // a violated constant row at node 0 (rows_at_node0)
         if (any_bad && stc == SMPC_STATUS_SUCCESS) stc = SMPC_STATUS_NAN;
         status[b] = stc;
         if (qp_iter) qp_iter[b] = it;

@@ -45,7 +45,7 @@ class Row(C.Structure):
 class ProblemDesc(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('nq', C.c_int32), ('N', C.c_int32), ('n_points', C.c_int32),
                 ('n_rows', C.c_int32), ('ee_point', C.c_int32), ('cost_kind', C.c_int32), ('hessian', C.c_int32),
-                ('nn_mode', C.c_int32), ('nn_dof', C.c_int32), ('qp_max_iter', C.c_int32), ('reserved0', C.c_int32),
+                ('nn_mode', C.c_int32), ('nn_dof', C.c_int32), ('qp_max_iter', C.c_int32), ('rows_at_node0', C.c_int32),
                 ('dt', C.c_double), ('Q', C.c_double), ('R', C.c_double), ('cost_scale_stage', C.c_double),
                 ('cost_scale_term', C.c_double), ('lm_stage', C.c_double), ('lm_term', C.c_double),
                 ('nn_eps', C.c_double), ('nn_soft_e', C.c_double), ('nn_soft_run', C.c_double),
@@ -103,7 +103,7 @@ CONTROLLER_KINDS = {
 class OcpProblem:
     """Everything the engine needs about one OCP family; ``desc`` is the C struct handed to ``smpc_create``."""
 
-    def __init__(self, params, controller='naive', cost='ext', N=None, chain=None):
+    def __init__(self, params, controller='naive', cost='ext', N=None, chain=None, rows_at_node0=None):
         if controller not in CONTROLLER_KINDS:
             raise ValueError(f'Controller {controller} not available')
         self.params = params
@@ -235,7 +235,11 @@ class OcpProblem:
         d.cost_kind = COST_ZERO if cost == 'zero' else COST_REACH
         d.hessian = HESS_EXACT if cost == 'ext' else HESS_GAUSS_NEWTON
         d.Q, d.R = params.Q_weight, params.R_weight
-        d.cost_scale_stage, d.cost_scale_term = params.dt, 1.0
+        # acados: stage costs x dt, terminal x 1 [EXT-UNVERIFIED]; NONLINEAR_LS is 1/2 |y|^2_W (cost_definition.py:61-81:
+        # W = diag(Q, R) -> gradient Q J^T delta, R u; Gauss-Newton Hessian Q J^T J, R I), EXTERNAL is the expression itself
+        # (cost_definition.py:91-96: Q |delta|^2 + R |u|^2 -> 2Q ..., 2R ...).  The engine differentiates Q|delta|^2 + R|u|^2.
+        half = 0.5 if cost == 'nls' else 1.0
+        d.cost_scale_stage, d.cost_scale_term = half * params.dt, half
         # controller.py:711 sets LM = 0 for the backup OCP, whose cost is zero as well: the QP Hessian vanishes and the
         # reference relies on HPIPM's internal primal regularisation [EXT-UNVERIFIED].  The engine states it: a 1e-4
         # diagonal makes the QP strictly convex (minimum-norm feasible correction of the guess) and well enough
@@ -250,6 +254,9 @@ class OcpProblem:
         for i in range(MAX_NQ):
             d.nn_mean[i], d.nn_std[i] = 0.0, 1.0
 
+        # collision rows at node 0: kept by the reference unless the run is noisy (controller.py:68-79)
+        d.rows_at_node0 = int(not float(getattr(params, 'noise', 0.0) or 0.0) > 0.0) if rows_at_node0 is None \
+            else int(bool(rows_at_node0))
         d.qp_max_iter = params.qp_max_iter
         d.qp_tol, d.qp_mu0 = 1e-8, 1.0
         self.desc = d

@@ -7,6 +7,7 @@ PyTorch is used for device memory only.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -51,6 +52,30 @@ class BatchedOcpSolver:
         if rc != 0:
             raise _lib.EngineError(f'engine error {rc}: {self.L.smpc_last_error(self.h).decode()}')
 
+    @contextlib.contextmanager
+    def _ordered(self, dev):
+        """Stream contract of the device path ("Streams"): the engine enqueues on its OWN non-blocking
+        stream, torch on its current stream.  On entry the engine's stream waits for everything already enqueued on
+        torch's current stream (inputs produced / buffers zero-filled by torch kernels); on exit torch's current stream
+        waits for the engine's work, so later torch ops -- and the caching allocator's reuse of temporaries freed after
+        the call -- are ordered behind it.  No host synchronisation.  A caller that already runs under
+        ``torch.cuda.stream(ExternalStream(smpc_stream))`` (bench.py) pays nothing."""
+        if not dev:
+            yield
+            return
+        import torch
+        if getattr(self, '_ext_stream', None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.L.smpc_stream(self.h), device=torch.device('cuda', self.device))
+        cur = torch.cuda.current_stream(self.device)
+        same = cur.cuda_stream == self._ext_stream.cuda_stream
+        if not same:
+            self._ext_stream.wait_stream(cur)
+        try:
+            yield
+        finally:
+            if not same:
+                cur.wait_stream(self._ext_stream)
+
     def set_mlp(self, net):
         """net: SafeSetNet (weights as numpy fp32) -- or anything with .weights/.biases lists of [out, in] / [out]."""
         Ws = [np.ascontiguousarray(w, np.float32) for w in net.weights]
@@ -82,7 +107,8 @@ class BatchedOcpSolver:
             return
         B = lo.shape[0]
         ptrs, dev, keep = self._prep([lo, hi], [(B, self.N + 1, self.nx)] * 2)
-        self._chk(self.L.smpc_set_instance_bounds(self.h, B, ptrs[0], ptrs[1], dev))
+        with self._ordered(dev):
+            self._chk(self.L.smpc_set_instance_bounds(self.h, B, ptrs[0], ptrs[1], dev))
 
     def sync(self):
         self._chk(self.L.smpc_sync(self.h))
@@ -153,7 +179,8 @@ class BatchedOcpSolver:
             if out is None:
                 out = (np.empty((B, N + 1, nx)), np.empty((B, N, nu)), np.empty(B, np.int32), np.empty(B, np.int32))
             op = [o.ctypes.data for o in out]
-        self._chk(self.L.smpc_solve_batch(self.h, B, *ptrs, *op, dev))
+        with self._ordered(dev):
+            self._chk(self.L.smpc_solve_batch(self.h, B, *ptrs, *op, dev))
         return out
 
     def eval_nodes(self, x_guess, u_guess, p):
@@ -165,7 +192,8 @@ class BatchedOcpSolver:
             import torch
             nd = NODE_EVAL_DTYPE.itemsize // 8
             raw = torch.zeros((B, N + 1, nd), dtype=torch.float64, device=x_guess.device)
-            self._chk(self.L.smpc_eval_nodes(self.h, B, *ptrs, raw.data_ptr(), 1))
+            with self._ordered(1):
+                self._chk(self.L.smpc_eval_nodes(self.h, B, *ptrs, raw.data_ptr(), 1))
             out = {}
             for name in NODE_EVAL_DTYPE.names:
                 dt, off = NODE_EVAL_DTYPE.fields[name][:2]
@@ -183,7 +211,8 @@ class BatchedOcpSolver:
         if not _is_torch(x_guess):
             x_guess = np.array(x_guess, np.float64, order='C', copy=True)
         ptrs, dev, keep = self._prep([x_guess, u_guess], [(B, self.N + 1, self.nx), (B, self.N, self.nu)])
-        self._chk(self.L.smpc_guess_correction(self.h, B, *ptrs, dev))
+        with self._ordered(dev):
+            self._chk(self.L.smpc_guess_correction(self.h, B, *ptrs, dev))
         return x_guess
 
     def provide_control(self, accept, x_temp, u_temp, x_guess, u_guess):
@@ -203,7 +232,8 @@ class BatchedOcpSolver:
         if not dev:
             # _prep may have re-wrapped the arrays; make sure outputs are the ones we return
             ptrs[3], ptrs[4], ptrs[5] = x_guess.ctypes.data, u_guess.ctypes.data, u_apply.ctypes.data
-        self._chk(self.L.smpc_provide_control(self.h, B, *ptrs, dev))
+        with self._ordered(dev):
+            self._chk(self.L.smpc_provide_control(self.h, B, *ptrs, dev))
         return x_guess, u_guess, u_apply
 
     def check_trajectory(self, x, x_min=None, x_max=None, tol_x=None, row_lb=None, row_ub=None, alpha=None,
@@ -223,10 +253,11 @@ class BatchedOcpSolver:
             import torch
             ok = torch.empty((B,), dtype=torch.int32, device=x.device)
             nn = torch.empty((B, n_nodes), dtype=torch.int32, device=x.device) if want_nn else None
-            self._chk(self.L.smpc_check_trajectory(self.h, B, n_nodes, x.data_ptr(), small[0].ctypes.data,
-                                                   small[1].ctypes.data, tol_x, small[2].ctypes.data,
-                                                   small[3].ctypes.data, alpha, tol_safe, ok.data_ptr(),
-                                                   nn.data_ptr() if want_nn else None, 1))
+            with self._ordered(1):
+                self._chk(self.L.smpc_check_trajectory(self.h, B, n_nodes, x.data_ptr(), small[0].ctypes.data,
+                                                       small[1].ctypes.data, tol_x, small[2].ctypes.data,
+                                                       small[3].ctypes.data, alpha, tol_safe, ok.data_ptr(),
+                                                       nn.data_ptr() if want_nn else None, 1))
             return (ok, nn) if want_nn else ok
         xx = np.ascontiguousarray(x, np.float64)
         ok = np.empty(B, np.int32)
@@ -254,8 +285,9 @@ class BatchedOcpSolver:
             for a, shp in ((x0, (B, nx)), (x_guess, (B, N + 1, nx)), (u_guess, (B, N, nu)), (p, (B, N + 1, 5))):
                 if tuple(a.shape) != shp or a.dtype != torch.float64 or not a.is_contiguous():
                     raise ValueError(f'rollout: expected a contiguous float64 tensor of shape {shp}')
-            self._chk(self.L.smpc_rollout_batch(self.h, B, n, x0.data_ptr(), x_guess.data_ptr(), u_guess.data_ptr(), p.data_ptr(),
-                                                jn, tn, xt.data_ptr(), ut.data_ptr(), st.data_ptr(), it.data_ptr(), 1))
+            with self._ordered(1):
+                self._chk(self.L.smpc_rollout_batch(self.h, B, n, x0.data_ptr(), x_guess.data_ptr(), u_guess.data_ptr(), p.data_ptr(),
+                                                    jn, tn, xt.data_ptr(), ut.data_ptr(), st.data_ptr(), it.data_ptr(), 1))
             return xt, ut, st, it, x_guess, u_guess
         x0 = np.ascontiguousarray(x0, np.float64)
         xg = np.array(x_guess, np.float64, order='C', copy=True)
@@ -286,8 +318,9 @@ class BatchedOcpSolver:
             ue = torch.empty_like(u)
             jn = joints_noisy.data_ptr() if joints_noisy is not None else None
             tn = tau_noise.data_ptr() if tau_noise is not None else None
-            self._chk(self.L.smpc_plant_step(self.h, B, x.data_ptr(), u.data_ptr(), jn, tn, xn.data_ptr(),
-                                             ue.data_ptr(), 1))
+            with self._ordered(1):
+                self._chk(self.L.smpc_plant_step(self.h, B, x.data_ptr(), u.data_ptr(), jn, tn, xn.data_ptr(),
+                                                 ue.data_ptr(), 1))
             return xn, ue
         xx, uu = np.ascontiguousarray(x, np.float64), np.ascontiguousarray(u, np.float64)
         xn, ue = np.empty_like(xx), np.empty_like(uu)

@@ -365,3 +365,52 @@ def test_mlp_tiled_gemm_path():
     a, b = s.eval_nodes(xg, ug, p), o.eval_nodes(xg, ug, p)
     assert _rel(a['nn_val'], b['nn_val']) < 2e-5
     assert _rel(a['nn_grad'][..., :12], b['nn_grad'][..., :12]) < 2e-4
+
+
+def test_eval_nodes_device_path_large_batch_stream_order():
+    """torch zero-fills the output on ITS stream while the engine writes it on its own non-blocking stream; the
+    solver orders the two (solver._ordered).  Large enough that an unordered fill would land after the engine's records."""
+    import torch
+    par, prob, net = make_problem('st', 'ext', N=30)
+    s = _solver(prob, net)
+    B = 4096
+    x0 = sample_instances(prob, 64, seed=4, vel_scale=0.2)[np.arange(B) % 64]
+    xg, ug, p = constant_guess(prob, x0)
+    ug += 1.0
+    a = s.eval_nodes(xg, ug, p)
+    dev = torch.device('cuda:0')
+    for rep in range(3):
+        # inputs produced by torch kernels right before the call, temporaries dropped right after it
+        b = s.eval_nodes(torch.tensor(xg, device=dev) * 1.0, torch.tensor(ug, device=dev) + 0.0, torch.tensor(p, device=dev).clone())
+        junk = torch.full((B, 31, 324), 7.0, dtype=torch.float64, device=dev)      # reuses freed blocks if unordered
+        tau = b['tau'].cpu().numpy()
+        assert np.array_equal(np.asarray(a['tau']), tau), rep
+        assert np.array_equal(np.asarray(a['row_grad']), b['row_grad'].cpu().numpy())
+        del junk
+
+
+def test_rows_at_node0_status_parity():
+    """controller.py:77-79: a start inside the collision band reports QP failure, engine and oracle alike."""
+    par, prob, net = make_problem('naive', 'ext', N=8)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    rng = np.random.default_rng(0)
+    qs = rng.uniform(prob.lbx[:6], prob.ubx[:6], (600, 6))
+    x0 = np.hstack([qs, np.zeros((600, 6))])
+    free = o.check_trajectory(x0[:, None, :], prob.x_min, prob.x_max, 0.0, prob.row_lb, prob.row_ub)
+    x0 = np.vstack([x0[~free][:12], x0[free][:12]])
+    assert len(x0) == 24
+    xg, ug, p = constant_guess(prob, x0)
+    sa, sb = s.solve(x0, xg, ug, p)[2], o.solve_batch(x0, xg, ug, p)[2]
+    assert np.array_equal(sa, sb) and np.all(sb[:12] == 4) and (sb[12:] == 0).sum() >= 10
+
+
+def test_timing_before_any_solve_is_a_state_error():
+    from safe_mpc_amd._lib import EngineError
+    par, prob, net = make_problem('naive', N=5)
+    s = _solver(prob, net)
+    s.enable_timing(True)
+    with pytest.raises(EngineError):
+        s.timing()
+    x0 = sample_instances(prob, 4, seed=0)
+    s.solve(x0, *constant_guess(prob, x0))
+    assert s.timing()['time_tot'] > 0

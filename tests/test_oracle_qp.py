@@ -105,3 +105,56 @@ def test_flag_switches_nn_row_off():
     a = o.solve_batch(x0, xg, ug, p)
     b = o_n.solve_batch(x0, xg, ug, p)
     assert np.array_equal(a[2], b[2]) and np.allclose(a[0], b[0], atol=1e-12) and np.allclose(a[1], b[1], atol=1e-12)
+
+
+def test_nls_cost_is_half_weighted_norm():
+    """acados NONLINEAR_LS is 1/2 |y|^2_W (cost_definition.py:61-81, W = diag(Q I3, R I)): the stage QP carries
+    dt (Q J^T J + LM), dt Q J^T delta, dt R on the u diagonal -- half of what the EXTERNAL cost Q|delta|^2 + R|u|^2 gives."""
+    N = 4
+    par, prob, net, o = _setup('naive', N, cost='nls')
+    assert prob.desc.cost_scale_stage == pytest.approx(0.5 * par.dt) and prob.desc.cost_scale_term == pytest.approx(0.5)
+    _, prob_e, _, o_e = _setup('naive', N, cost='ext')
+    assert prob_e.desc.cost_scale_stage == pytest.approx(par.dt) and prob_e.desc.cost_scale_term == pytest.approx(1.0)
+    x0 = sample_instances(prob, 1, seed=3)
+    xg, ug, p = constant_guess(prob, x0)
+    ug += 1.5
+    qp = o.build_qp(x0[0], xg[0], ug[0], p[0])
+    # finite-difference Jacobian of the EE point
+    ee = lambda q: o.points(q)[prob.desc.ee_point]
+    q, eps = x0[0, :6], 1e-6
+    J = np.stack([(ee(q + eps * np.eye(6)[j]) - ee(q - eps * np.eye(6)[j])) / (2 * eps) for j in range(6)], axis=1)
+    delta = ee(q) - prob.ee_ref
+    Q, R, dt, lm = par.Q_weight, par.R_weight, par.dt, par.levenberg_marquardt
+    Hqq = qp['H'][1, 6:12, 6:12]
+    assert np.allclose(Hqq, dt * (Q * J.T @ J + lm * np.eye(6)), atol=1e-6)
+    assert np.allclose(qp['g'][1, 6:12], dt * Q * J.T @ delta, atol=1e-6)
+    assert np.allclose(np.diag(qp['H'][1, :6, :6]), dt * (R + lm))
+    assert np.allclose(qp['g'][1, :6], dt * R * ug[0, 1])
+    assert np.allclose(qp['H'][N, :6, :6], Q * J.T @ J + lm * np.eye(6), atol=1e-6)     # terminal: nu = 0, no dt
+
+
+def test_rows_at_node0_report_qp_failure():
+    """controller.py:77-79: without --noise the collision rows stay in con_h_expr_0; x_0 is pinned, so a start inside the
+    2 x collision_margin band makes the QP infeasible (status 4) -- with --noise > 0 they are dropped (controller.py:69-73)."""
+    from safe_mpc_amd.problem import OcpProblem
+    par, prob, net, o = _setup('naive', 5)
+    assert prob.desc.rows_at_node0 == 1
+    rng = np.random.default_rng(0)
+    bad = None
+    for q in rng.uniform(prob.lbx[:6], prob.ubx[:6], (4000, 6)):
+        x = np.concatenate([q, np.zeros(6)])
+        if not o.check_trajectory(x[None, None], prob.x_min, prob.x_max, 0.0, prob.row_lb, prob.row_ub)[0]:
+            bad = x
+            break
+    assert bad is not None
+    good = sample_instances(prob, 1, seed=0)[0]
+    x0 = np.stack([bad, good])
+    xg, ug, p = constant_guess(prob, x0)
+    st = o.solve_batch(x0, xg, ug, p)[2]
+    assert st[0] == 4 and st[1] == 0
+    par.noise = 5.0
+    prob_n = OcpProblem(par, 'naive', 'ext', N=5)
+    assert prob_n.desc.rows_at_node0 == 0
+    o_n = Oracle(prob_n)
+    assert o_n.solve_batch(x0[1:], xg[1:], ug[1:], p[1:])[2][0] == 0
+    par.noise = 0.0
