@@ -192,6 +192,12 @@ int smpc_set_stage_bounds(smpc_handle* h, const double* lo, const double* hi);
  * same B until cleared with lo = hi = NULL.  Pointers follow on_device like smpc_solve_batch; the handle keeps a copy. */
 int smpc_set_instance_bounds(smpc_handle* h, int B, const double* lo, const double* hi, int on_device);
 
+/* replaces ocp_solver.cost_set(k,'zl'/'zu',v) (controller.py:455-468, 526-527): L1 penalty of the slack on the safe-set row of
+ * node k, for the nodes where the formulation made that row soft (nn_soft_e / nn_soft_run >= 0; a hard row has no slack and
+ * acados' arrays for it are empty).  zl is [N+1] host doubles shared by all instances (entry 0 unused); NULL restores the
+ * descriptor's weights. */
+int smpc_set_slack_weights(smpc_handle* h, const double* zl);
+
 /* ---- the hot path --------------------------------------------------------------------------------------------- */
 /* One SQP-RTI solve of B independent OCPs: replaces reset / constraints_set(0,lbx|ubx,x0) / set(i,x|u|p) / solve /
  * get(i,x|u) of controller.py:141-164 for B instances in one call.

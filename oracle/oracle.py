@@ -92,6 +92,14 @@ class Oracle:
             assert lo.shape == (self.N + 1, self.nx)
             self.L.orc_set_stage_bounds(self.h, _p(lo), _p(hi))
 
+    def set_slack_weights(self, zl=None):
+        if zl is None:
+            self.L.orc_set_slack_weights(self.h, None)
+        else:
+            zl = _f64(zl)
+            assert zl.shape == (self.N + 1,)
+            self.L.orc_set_slack_weights(self.h, _p(zl))
+
     def set_instance_bounds(self, lo=None, hi=None):
         if lo is None:
             self.L.orc_set_instance_bounds(self.h, 0, None, None)

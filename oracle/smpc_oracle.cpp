@@ -838,7 +838,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
 }
 
 /* build the stage QP of one instance from node evaluations */
-bool build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const double* hi_st,
+bool build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const double* hi_st, const double* zl_st,
               const std::vector<smpc_node_eval>& ev, const double* x0, const double* xg, const double* ug,
               const double* p, std::vector<Stage>& S, double* dx0) {
     int nq = D.nq, nx = 2 * nq, nu = nq;
@@ -929,6 +929,7 @@ bool build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const doub
             s.has_lo[r] = on;
             s.has_hi[r] = false;
             double w = k == N ? D.nn_soft_e : D.nn_soft_run;
+            if (zl_st && w >= 0.0) w = zl_st[k];   /* cost_set(k,'zl',.) (controller.py:455-468) on a soft row */
             s.soft[r] = on ? w : -1.0;
             r++;
         }
@@ -943,6 +944,7 @@ struct Oracle {
     int N;
     std::vector<double> lo_st, hi_st;  // [N+1][nx]
     std::vector<double> lo_b, hi_b;    // [B][N+1][nx] per-instance bounds (RealReceding), empty = none
+    std::vector<double> zl;            // [N+1] run-time slack weights of soft rows, empty = descriptor's
     int inst_B = 0;
     void reset_bounds() {
         int nx = 2 * D.nq;
@@ -1005,6 +1007,13 @@ int orc_set_stage_bounds(void* h, const double* lo, const double* hi) {
     size_t n = (size_t)(o->N + 1) * 2 * o->D.nq;
     o->lo_st.assign(lo, lo + n);
     o->hi_st.assign(hi, hi + n);
+    return 0;
+}
+
+int orc_set_slack_weights(void* h, const double* zl) {
+    Oracle* o = (Oracle*)h;
+    if (!zl) o->zl.clear();
+    else o->zl.assign(zl, zl + o->N + 1);
     return 0;
 }
 
@@ -1082,7 +1091,7 @@ int orc_solve_batch(void* h, int B, const double* x0, const double* xg, const do
         const size_t boff = (size_t)b * (N + 1) * nx;
         const double* blo = o->inst_B == B ? o->lo_b.data() + boff : o->lo_st.data();
         const double* bhi = o->inst_B == B ? o->hi_b.data() + boff : o->hi_st.data();
-        const bool infeasible0 = build_qp(D, N, blo, bhi, ev, x0 + (size_t)b * nx, xb, ub, pb, S, dx0);
+        const bool infeasible0 = build_qp(D, N, blo, bhi, o->zl.empty() ? nullptr : o->zl.data(), ev, x0 + (size_t)b * nx, xb, ub, pb, S, dx0);
         int it = 0;
         double res[2] = {0, 0};
         int qs = qp_ipm(S, N, nx, nu, D.dt, dx0, qo, &it, res);
@@ -1127,7 +1136,7 @@ int orc_build_qp(void* h, const double* x0, const double* xg, const double* ug, 
         eval_node(D, &o->net, k, N, xg + (size_t)k * nx, k < N ? ug + (size_t)k * nu : nullptr,
                   p + (size_t)k * SMPC_NP, &ev[k]);
     std::vector<Stage> S(N + 1);
-    build_qp(D, N, o->lo_st.data(), o->hi_st.data(), ev, x0, xg, ug, p, S, dx0);
+    build_qp(D, N, o->lo_st.data(), o->hi_st.data(), o->zl.empty() ? nullptr : o->zl.data(), ev, x0, xg, ug, p, S, dx0);
     for (int k = 0; k <= N; k++) {
         std::memcpy(Hh + (size_t)k * MAXZ * MAXZ, S[k].H, sizeof(S[k].H));
         std::memcpy(g + (size_t)k * MAXZ, S[k].g, sizeof(S[k].g));

@@ -15,7 +15,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 LIB_PATH = os.environ.get('SMPC_HIP_LIB') or os.path.join(_CSRC, 'libsmpc_hip.so')
 
 SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error', 'smpc_set_mlp', 'smpc_set_horizon',
-           'smpc_set_stage_bounds', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',
+           'smpc_set_stage_bounds', 'smpc_set_slack_weights', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',
            'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_rollout_batch', 'smpc_sync', 'smpc_stream',
            'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing']
 
@@ -54,6 +54,7 @@ def lib():
     L.smpc_set_mlp.argtypes = [vp, C.c_int, i32p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int]
     L.smpc_set_horizon.argtypes = [vp, C.c_int]
     L.smpc_set_stage_bounds.argtypes = [vp, dp, dp]
+    L.smpc_set_slack_weights.argtypes = [vp, dp]
     L.smpc_set_instance_bounds.argtypes = [vp, C.c_int, dp, dp, C.c_int]
     L.smpc_solve_batch.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, C.c_int]
     L.smpc_eval_nodes.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int]

@@ -27,6 +27,7 @@ struct smpc_handle {
     hipStream_t stream = nullptr;
     smpc_problem_desc* d_desc = nullptr;
     double *d_lo = nullptr, *d_hi = nullptr;  // [N+1][nx] stage bounds
+    double* d_zl = nullptr;                   // [N+1] run-time slack weights of the soft safe-set rows (cost_set), or null
     double *d_lo_b = nullptr, *d_hi_b = nullptr;  // [B][N+1][nx] per-instance bounds (RealReceding), valid for inst_B
     int inst_B = 0;
     // network
@@ -280,7 +281,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
 #define SMPC_QP_LAUNCH(MR_)                                                                                                        \
     do {                                                                                                                           \
         hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
-                           bhi, h->d_ev, h->d_ws, bstride);                                                                        \
+                           bhi, h->d_zl, h->d_ev, h->d_ws, bstride);                                                               \
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                           \
         hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
                            ug, h->d_ws, xo, uo, st, it, order, h->d_last_it);                                                      \
@@ -366,7 +367,7 @@ void smpc_destroy(smpc_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->d_desc, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
+    void* ptrs[] = {h->d_desc, h->d_zl, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
                     h->d_st, h->d_it, h->d_S, h->d_y, h->d_GS, h->d_dA, h->d_dB, h->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < SMPC_MAX_LAYERS; l++) {
@@ -428,6 +429,7 @@ int smpc_set_horizon(smpc_handle* h, int N) {
     (void)hipSetDevice(h->device);
     h->N = N;
     h->inst_B = 0;
+    if (h->d_zl) { (void)hipFree(h->d_zl); h->d_zl = nullptr; }   // per-node weights belong to the old horizon
     h->ws_bytes = 0;  // workspace layout, linearisation records and IO staging are sized by N
     h->capIO = 0;
     return upload_bounds(h, nullptr, nullptr);
@@ -438,6 +440,22 @@ int smpc_set_stage_bounds(smpc_handle* h, const double* lo, const double* hi) {
     if ((lo == nullptr) != (hi == nullptr)) return fail(h, SMPC_EINVAL, "lo and hi must both be given or both be NULL");
     (void)hipSetDevice(h->device);
     return upload_bounds(h, lo, hi);
+}
+
+int smpc_set_slack_weights(smpc_handle* h, const double* zl) {
+    if (!h) return SMPC_EINVAL;
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!zl) {
+        if (h->d_zl) { (void)hipFree(h->d_zl); h->d_zl = nullptr; }
+        return SMPC_OK;
+    }
+    for (int k = 1; k <= h->N; k++)
+        if (!(zl[k] >= 0.0)) return fail(h, SMPC_EINVAL, "slack weight of node %d is negative or NaN", k);
+    int rc;
+    if ((rc = dev_alloc(h, &h->d_zl, (size_t)h->N + 1))) return rc;
+    HIPCHK(h, hipMemcpy(h->d_zl, zl, sizeof(double) * (h->N + 1), hipMemcpyHostToDevice));
+    return SMPC_OK;
 }
 
 int smpc_set_instance_bounds(smpc_handle* h, int B, const double* lo, const double* hi, int on_device) {

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
                                                  const double* __restrict__ x0, const double* __restrict__ xg,
                                                  const double* __restrict__ ug, const double* __restrict__ pp,
                                                  const double* __restrict__ lo_st, const double* __restrict__ hi_st,
-                                                 const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
+                                                 const double* __restrict__ zl_st, const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
                                                  long bnd_stride) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, NL = 32;
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
     const bool reach = D->cost_kind == SMPC_COST_REACH;
     bool nn_on = false;
     if (D->nn_mode != SMPC_NN_NONE && k >= 1 && (D->nn_mode == SMPC_NN_ALL || last)) nn_on = pk[4] > 0.0;
-    const double wsoft = nn_on ? (last ? D->nn_soft_e : D->nn_soft_run) : -1.0;
+    double wsoft = nn_on ? (last ? D->nn_soft_e : D->nn_soft_run) : -1.0;
+    if (zl_st && wsoft >= 0.0) wsoft = zl_st[k];    // cost_set(k, 'zl', .) on a row the formulation made soft
 
     // general rows, row-major [torque | collision | safe-set] x [u q v]
     for (int el = hl; el < NRC * NZP; el += 32) {

@@ -100,6 +100,15 @@ class BatchedOcpSolver:
         assert lo.shape == (self.N + 1, self.nx) and hi.shape == lo.shape
         self._chk(self.L.smpc_set_stage_bounds(self.h, lo.ctypes.data, hi.ctypes.data))
 
+    def set_slack_weights(self, zl=None):
+        """cost_set(k, 'zl', v) for every node at once (controller.py:455-468): zl[N+1], None restores the formulation's."""
+        if zl is None:
+            self._chk(self.L.smpc_set_slack_weights(self.h, None))
+            return
+        zl = np.ascontiguousarray(zl, np.float64)
+        assert zl.shape == (self.N + 1,)
+        self._chk(self.L.smpc_set_slack_weights(self.h, zl.ctypes.data))
+
     def set_instance_bounds(self, lo=None, hi=None):
         """Per-instance stage bounds [B, N+1, nx] (RealReceding's state tube, controller.py:530-536); None clears."""
         if lo is None:

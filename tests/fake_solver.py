@@ -22,6 +22,12 @@ class OracleSolver:
     def set_instance_bounds(self, lo=None, hi=None):
         self.o.set_instance_bounds(lo, hi)
 
+    def set_slack_weights(self, zl=None):
+        self.o.set_slack_weights(zl)
+
+    def enable_timing(self, on=True):
+        pass
+
     def solve(self, x0, xg, ug, p, out=None):
         x, u, st, it = self.o.solve_batch(x0, xg, ug, p)
         if self.scripted_status:

@@ -1,0 +1,157 @@
+"""HipOcpSolver: the AcadosOcpSolver-shaped seam.  The call sequences below are the reference's own:
+AbstractController.solve (controller.py:141-165), RecedingController.step (:452-469), RealReceding.step (:526-536),
+resetHorizon (:208-209), getTime (:193).  CPU: through the oracle test double; -m gpu: through the C ABI, bitwise equal to
+BatchedOcpSolver at B = 1."""
+import numpy as np
+import pytest
+
+from conftest import constant_guess, make_problem, sample_instances
+
+
+def reference_solve_sequence(ocp_solver, N, x0, x_guess, u_guess, traj, alpha):
+    """controller.py:141-165, line for line."""
+    ocp_solver.reset()
+    ocp_solver.constraints_set(0, 'lbx', x0)
+    ocp_solver.constraints_set(0, 'ubx', x0)
+    for i in range(N):
+        ocp_solver.set(i, 'x', x_guess[i])
+        ocp_solver.set(i, 'u', u_guess[i])
+    ocp_solver.set(N, 'x', x_guess[-1])
+    for i in range(N + 1):
+        ocp_solver.set(i, 'p', np.hstack([traj[:, i], [alpha, ocp_solver.get(i, 'p')[-1]]]))
+    status = ocp_solver.solve()
+    x_temp, u_temp = np.zeros((N + 1, x_guess.shape[1])), np.zeros((N, u_guess.shape[1]))
+    for i in range(N):
+        x_temp[i] = ocp_solver.get(i, 'x')
+        u_temp[i] = ocp_solver.get(i, 'u')
+    x_temp[-1] = ocp_solver.get(N, 'x')
+    return status, x_temp, u_temp
+
+
+def _cases(make_batched):
+    """Runs the reference call sequences through a facade built on make_batched(prob, net) and returns comparisons."""
+    from safe_mpc_amd.acados_facade import HipOcpSolver
+    out = []
+    # --- 1. plain solve, controller 'st' (soft terminal row) -----------------------------------------------------------------
+    par, prob, net = make_problem('st', 'ext', N=12)
+    bs = make_batched(prob, net)
+    f = HipOcpSolver(prob, net, batched=bs)
+    x0 = sample_instances(prob, 1, seed=3, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    traj = np.tile(prob.ee_ref, (13, 1)).T
+    st, xt, ut = reference_solve_sequence(f, 12, x0[0], xg[0], ug[0], traj, par.alpha)
+    xb, ub, sb, ib = bs.solve(x0, xg, ug, p)
+    out.append(('st', st == sb[0] and np.array_equal(xt, xb[0]) and np.array_equal(ut, ub[0])))
+    assert f.get_status() == st and f.get_stats('sqp_iter') == 1 and f.get_stats('qp_iter')[0] == ib[0]
+    for fld in f.TIME_FIELDS:
+        assert f.get_stats(fld) >= 0.0
+    # second solve from the shifted solution with a different measured state (the closed loop's pattern)
+    x1 = xt[1] + 1e-3
+    xg2 = np.vstack([xt[1:], xt[-1:]])[None]
+    ug2 = np.vstack([ut[1:], ut[-1:]])[None]
+    st, xt2, ut2 = reference_solve_sequence(f, 12, x1, xg2[0], ug2[0], traj, par.alpha)
+    xb, ub, sb, ib = bs.solve(x1[None], xg2, ug2, p)
+    out.append(('st second step', st == sb[0] and np.array_equal(xt2, xb[0]) and np.array_equal(ut2, ub[0])))
+    # --- 2. RecedingController.step's flag / slack-weight toggling (controller.py:452-469) -------------------------------------
+    par, prob, net = make_problem('receding', 'ext', N=10)
+    bs = make_batched(prob, net)
+    f = HipOcpSolver(prob, net, batched=bs)
+    N, r = 10, 4
+    x0 = sample_instances(prob, 1, seed=4, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    zl_size = 0                                          # runningSetConstraint(soft=False): no running slack (controller.py:441)
+    for i in range(1, N):
+        if i != r:
+            f.cost_set(i, 'zl', np.zeros((zl_size,)))
+            f.cost_set(i, 'zu', np.zeros((zl_size,)))
+            f.set(i, 'p', np.hstack([prob.ee_ref, [par.alpha, -1.0]]))
+    f.cost_set(N, 'zl', par.ws_t * np.ones((1,)))
+    f.cost_set(N, 'zu', par.ws_t * np.ones((1,)))
+    f.set(N, 'p', np.hstack([prob.ee_ref, [par.alpha, 1.0]]))
+    f.cost_set(r, 'zl', par.ws_r * np.ones((zl_size,)))
+    f.set(r, 'p', np.hstack([prob.ee_ref, [par.alpha, 1.0]]))
+    traj = np.tile(prob.ee_ref, (N + 1, 1)).T
+    st, xt, ut = reference_solve_sequence(f, N, x0[0], xg[0], ug[0], traj, par.alpha)
+    p[:, 1:N, 4] = -1.0
+    p[:, r, 4] = 1.0
+    xb, ub, sb, ib = bs.solve(x0, xg, ug, p)
+    out.append(('receding flags', st == sb[0] and np.array_equal(xt, xb[0]) and np.array_equal(ut, ub[0])))
+    # a different terminal slack weight through cost_set reaches the QP: equal to a formulation built with that weight
+    f.cost_set(N, 'zl', 3.0 * np.ones((1,)))
+    st2, xt2, ut2 = reference_solve_sequence(f, N, x0[0], xg[0], ug[0], traj, par.alpha)
+    par3, prob3, net3 = make_problem('receding', 'ext', N=10, ws_t=3.0)
+    bs3 = make_batched(prob3, net3)
+    xb3, ub3, sb3, _ = bs3.solve(x0, xg, ug, p)
+    out.append(('cost_set zl', st2 == sb3[0] and np.array_equal(ut2, ub3[0])))
+    # --- 3. RealReceding.step's state tube (controller.py:526-536) --------------------------------------------------------------
+    par, prob, net = make_problem('real_receding', 'ext', N=10)
+    bs = make_batched(prob, net)
+    f = HipOcpSolver(prob, net, batched=bs)
+    x0 = sample_instances(prob, 1, seed=5, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    xg[0, 1:] += 1e-3 * np.random.default_rng(0).standard_normal((10, 12))
+    f.cost_set(N, 'zl', par.ws_t * np.ones((0,)))        # hard terminal row: zl_e is empty (controller.py:514-515)
+    f.cost_set(N, 'zu', par.ws_t * np.ones((0,)))
+    r = 3
+    f.constraints_set(r, 'lbx', xg[0, r + 1] - 1e-3)
+    f.constraints_set(r, 'ubx', xg[0, r + 1] + 1e-3)
+    for i in range(N):
+        if i != r:
+            f.constraints_set(i, 'lbx', prob.x_min)
+            f.constraints_set(i, 'ubx', prob.x_max)
+    st, xt, ut = reference_solve_sequence(f, N, x0[0], xg[0], ug[0], traj, par.alpha)
+    lo = np.broadcast_to(prob.x_min, (1, N + 1, 12)).copy()
+    hi = np.broadcast_to(prob.x_max, (1, N + 1, 12)).copy()
+    lo[:, N], hi[:, N] = prob.lbx_e, prob.ubx_e
+    lo[0, r], hi[0, r] = xg[0, r + 1] - 1e-3, xg[0, r + 1] + 1e-3
+    bs.set_stage_bounds(None, None)
+    bs.set_instance_bounds(lo, hi)
+    xb, ub, sb, ib = bs.solve(x0, xg, ug, p)
+    bs.set_instance_bounds(None, None)
+    out.append(('real_receding tube', st == sb[0] and np.array_equal(xt, xb[0]) and np.array_equal(ut, ub[0])))
+    if st == 0:
+        assert np.all(np.abs(xt[r] - xg[0, r + 1]) <= 1e-3 + 1e-7)
+    # --- 4. resetHorizon (controller.py:205-209) ------------------------------------------------------------------------------
+    f.set_new_time_steps(np.full(6, par.dt))
+    f.update_qp_solver_cond_N(6)
+    assert f.N == 6 and f.get(6, 'x').shape == (12,)
+    with pytest.raises(ValueError):
+        f.get(7, 'x')
+    with pytest.raises(NotImplementedError):
+        f.set_new_time_steps(np.full(6, 2 * par.dt))
+    traj6 = np.tile(prob.ee_ref, (7, 1)).T
+    st, xt, ut = reference_solve_sequence(f, 6, x0[0], xg[0, :7], ug[0, :6], traj6, par.alpha)
+    xb, ub, sb, ib = bs.solve(x0, xg[:, :7].copy(), ug[:, :6].copy(), p[:, :7].copy())
+    out.append(('new horizon', st == sb[0] and np.array_equal(xt, xb[0]) and np.array_equal(ut, ub[0])))
+    return out
+
+
+def test_facade_misuse_raises():
+    from fake_solver import OracleSolver
+    from safe_mpc_amd.acados_facade import HipOcpSolver
+    par, prob, net = make_problem('naive', 'ext', N=5)
+    f = HipOcpSolver(prob, net, batched=OracleSolver(prob, net))
+    with pytest.raises(ValueError):
+        f.solve()                                   # x0 never given
+    with pytest.raises(ValueError):
+        f.set(0, 'lam', np.zeros(3))
+    with pytest.raises(ValueError):
+        f.set(5, 'u', np.zeros(6))                  # no control at the terminal node
+    with pytest.raises(ValueError):
+        f.constraints_set(1, 'lbx', np.zeros(3))
+    with pytest.raises(ValueError):
+        f.get_stats('nonsense')
+    assert f.get_status() == 4                      # controller.py:125
+
+
+def test_facade_reference_call_sequences_on_oracle_double():
+    from fake_solver import OracleSolver
+    for name, same in _cases(lambda prob, net: OracleSolver(prob, net)):
+        assert same, name
+
+
+@pytest.mark.gpu
+def test_facade_reference_call_sequences_on_engine():
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    for name, same in _cases(lambda prob, net: BatchedOcpSolver(prob, net)):
+        assert same, name
