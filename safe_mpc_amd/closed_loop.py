@@ -171,6 +171,7 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
     u_abort = np.zeros((B, Nb, nu))
     collisions, viable, x_viable_log = set(), set(), []
     x_cur = x_sim[:, 0].copy()
+    r_log = np.full((B, n_steps, 1), -1, np.int64)
 
     for j in range(n_steps):
         u = np.zeros((B, nu))
@@ -195,6 +196,8 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
         # --- instances under MPC (mpc.py:151)
         stepping = alive & ~sa
         if stepping.any():
+            if hasattr(ctrl, 'r'):
+                r_log[:, j, 0] = np.where(stepping, ctrl.r, -1)
             u_m, ab = _masked_step(ctrl, x_cur, stepping)
             u = np.where(stepping[:, None], u_m, u)
             new_abort = ab & stepping
@@ -243,7 +246,9 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
     viable_idx = sorted(i for i in viable if i not in collisions)
     coll_idx = sorted(collisions)
     unconv_idx = sorted(set(range(B)) - set(conv_idx) - set(coll_idx) - set(viable_idx))
-    return {'x': x_sim, 'u': u_log, 'r': np.full((B, n_steps, 1), np.nan), 'conv_idx': conv_idx,
+    # 'r': the reference allocates r_index as NaN and never writes it (mpc.py:116, 281) -- kept NaN for format parity; the
+    # receding index actually used at every step is returned next to it as 'r_receding' (-1 where the policy has none)
+    return {'x': x_sim, 'u': u_log, 'r': np.full((B, n_steps, 1), np.nan), 'r_receding': r_log, 'conv_idx': conv_idx,
             'collisions_idx': coll_idx, 'unconv_idx': unconv_idx, 'viable_idx': viable_idx,
             'x_viable': np.asarray(x_viable_log)}
 
