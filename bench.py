@@ -9,16 +9,26 @@ guessCorrection -> SQP-RTI solve (linearise, MLP, QP) -> accept test -> provideC
 
 Workload (config.workload = "C1"): Z1-class 6-DoF, N = 30, 4096 OCP instances per GPU, controller 'st'
 (terminal soft safe-set row through the 12-256-256-256-1 GELU MLP), EXTERNAL cost with exact Hessian, 6 capsule pairs,
-Halton initial states, constant first guess -- SURVEY 8(d).  Weak scaling: every rank owns 4096 instances; the only
-exchange is one RCCL gather of the applied controls + statuses per step.
+Halton initial states, constant first guess -- SURVEY 8(d).
+  --scaling weak   (default) every rank owns 4096 instances
+  --scaling strong 4096 instances in total, split over the ranks by shard_range (the north star's wording)
+The only exchange is one RCCL gather of the applied controls + statuses per step.
+
+Launch: `python bench.py --gpus N` starts N fresh child processes itself (one per GPU, before anything touches a GPU) when
+no launcher environment is present; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it
+reads RANK / LOCAL_RANK / WORLD_SIZE.  Asking for more GPUs than are visible is an error, never a silent 1-GPU run.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline:     algorithmic HBM bytes of the dominant kernel (k_qp_ipm) / its HIP-event duration vs 8 TB/s
-  cpu_baseline: the CPU oracle (a port, not acados) timed on this host on a bounded sample of the same workload.
+  roofline:     algorithmic HBM bytes of the dominant kernel (k_qp_ipm) / its HIP-event duration vs 8 TB/s, the FP64 / MFMA
+                FLOP fractions SURVEY 8(d) asks for, and the launch's load balance (span / mean busy time of an instance)
+  cpu_baseline: the CPU oracle (a port, not acados) timed on this host on a bounded sample of the SAME closed-loop state:
+                all-core throughput and 1-thread single-instance latency (p50 / p99, comparable to scripts/mpc.py:300-303).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,6 +44,20 @@ B_PER_GPU = 4096
 HORIZON = 30
 CONTROLLER = os.environ.get('SMPC_BENCH_CONTROLLER', 'st')   # 'constraint_everywhere': the safe-set row on ALL nodes (reported separately)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TF = 157.3       # same guide: FP32 matrix (v_mfma_f32_32x32x2_f32) = FP32 vector peak
+FP64_VALU_PEAK_TF = 78.6       # vendor figure for MI355X vector FP64 (the guide does not list it): 256 CUs x 4 SIMDs
+                               # x 16 FP64 FMA lanes/clk x 2 flop x 2.4 GHz
+
+
+def qp_flops_per_iteration(nq, N, nh):
+    """N [7/3 nx^3 + 4 nx^2 nu + 2 nx nu^2 + nu^3/3 + (nx+nu)^2 (nh+nx)]  (0.486 MFLOP at Z1, N = 30, nh = 13)"""
+    nx, nu = 2 * nq, nq
+    return N * (7.0 / 3.0 * nx ** 3 + 4.0 * nx * nx * nu + 2.0 * nx * nu * nu + nu ** 3 / 3.0 + (nx + nu) ** 2 * (nh + nx))
+
+
+def mlp_flops_per_row(nq, H=256, L=3):
+    """forward + one VJP = 4 (2 nq H + (L-1) H^2 + H)  (537 600 at nq = 6)"""
+    return 4.0 * (2 * nq * H + (L - 1) * H * H + H)
 
 
 def algorithmic_bytes(nq, N):
@@ -84,24 +108,64 @@ def initial_states(solver, prob, B, rank):
     return np.vstack(xs)[:B]
 
 
-def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=12.0):
-    """CPU port (oracle/) on this host's cores: bounded sample of the same workload, same first RTI step."""
+def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=10.0, latency_solves=160):
+    """CPU port (oracle/) on this host's cores, on a bounded sample of the closed-loop state the GPU leg was timed on:
+    (1) OpenMP over instances on all cores -> instance-steps/s; (2) ONE thread, ONE instance per call -> latency p50 / p99
+    (what scripts/mpc.py:300-303 prints per step for the reference's sequential loop)."""
     from oracle.oracle import Oracle, build
     build()
     o = Oracle(prob, (net.weights, net.biases))
     cores = len(os.sched_getaffinity(0))
-    chunk, done = min(len(x0), 8 * cores), 0
+    chunk, done, iters = min(len(x0), 8 * cores), 0, 0
     o.solve_batch(x0[:cores], xg[:cores], ug[:cores], p[:cores])      # warm the code path
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:                         # cycle through the sample until the budget is used
         lo = done % (len(x0) - chunk + 1)
         sl = slice(lo, lo + chunk)
-        o.solve_batch(x0[sl], xg[sl], ug[sl], p[sl])
+        iters += int(o.solve_batch(x0[sl], xg[sl], ug[sl], p[sl])[3].sum())
         done += chunk
     dt = time.perf_counter() - t0
+    lat = []
+    for i in range(latency_solves):                                    # B = 1: the OpenMP loop has one iteration = one thread
+        j = i % len(x0)
+        t1 = time.perf_counter()
+        o.solve_batch(x0[j:j + 1], xg[j:j + 1], ug[j:j + 1], p[j:j + 1])
+        lat.append(time.perf_counter() - t1)
+    lat = np.sort(np.array(lat)) * 1e3
     return {'value': done / dt, 'unit': 'instance-steps/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{done} instance-solves drawn cyclically from {len(x0)} C1 instances (first RTI step), OpenMP over instances, '
-                      f'{dt:.1f} s; oracle/smpc_oracle.cpp -O3, a CPU restatement -- not acados'}
+            'mean_ipm_iterations': iters / max(done, 1),
+            'latency_1thread_ms': {'p50': float(np.quantile(lat, 0.5)), 'p99': float(np.quantile(lat, 0.99)),
+                                   'mean': float(lat.mean()), 'solves': int(len(lat))},
+            'sample': f'{done} instance-solves drawn cyclically from {len(x0)} C1 instances in the closed-loop state the GPU leg ended '
+                      f'in (same x, shifted guess, p), OpenMP over instances, {dt:.1f} s; then {len(lat)} single-instance solves on one '
+                      f'thread; oracle/smpc_oracle.cpp -O3 (dual-number derivatives, dense stage algebra), a CPU restatement -- not acados'}
+
+
+def launch_children(args):
+    """`python bench.py --gpus N` without a launcher: N fresh children, one per GPU, started before this process touches a GPU
+    (device_count() does not initialise one).  Children inherit stdout: rank 0 prints the JSON line."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} requested but {have} GPU(s) visible; refusing to run on fewer\n')
+        return 2
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for pr in procs:
+            rc = max(rc, abs(pr.wait()))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
 
 
 def main():
@@ -115,7 +179,13 @@ def main():
     ap.add_argument('--streams', type=int, default=2,
                     help='sub-batches per GPU, each on its own HIP stream (fills the tail of the slowest instances)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='weak: --batch instances per GPU; strong: --batch instances in total, split over the GPUs')
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_children(args))
 
     # The contract is ONE JSON line on stdout.  RCCL prints a version banner to stdout when its first communicator comes
     # up: keep the real stdout aside for the result line and send everything else written to fd 1 to stderr.
@@ -128,8 +198,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (or none: bench.py spawns them)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
     torch.cuda.set_device(local)
@@ -143,12 +213,21 @@ def main():
     from safe_mpc_amd.sharding import gather_to_root, shard_range
     from safe_mpc_amd.solver import BatchedOcpSolver
     par, prob, net = build_problem()
-    B, N, nx, nu = args.batch, HORIZON, prob.nx, prob.nu
+    if args.scaling == 'strong':
+        lo_r, hi_r = shard_range(args.batch, world, rank)
+        B = hi_r - lo_r
+        B_total = args.batch
+    else:
+        B, B_total = args.batch, args.batch * world
+    if B < 1:
+        raise SystemExit('strong scaling: fewer instances than ranks')
+    N, nx, nu = HORIZON, prob.nx, prob.nu
     S = max(1, min(args.streams, B // 256 or 1))
 
     # one solver handle (= one HIP stream + its own workspace) per sub-batch: independent instances, so the sub-batches
     # advance independently and the hardware overlaps the long tail of one with the bulk of another
     solvers = [BatchedOcpSolver(prob, net, device=local) for _ in range(S)]
+    # (strong scaling: every rank draws from its own stretch of the Halton sequence, like weak -- instances are independent)
     x0_h = initial_states(solvers[0], prob, B, rank)
     xg_h = np.repeat(x0_h[:, None, :], N + 1, axis=1)
     ug_h = np.zeros((B, N, nu))
@@ -174,6 +253,15 @@ def main():
             sb.payload = torch.empty((sb.n, nu + 1), dtype=torch.float64, device=dev)
         subs.append(sb)
     gather_in = torch.empty((B, nu + 1), dtype=torch.float64, device=dev)
+    if args.scaling == 'strong':
+        sizes_all = [shard_range(args.batch, world, r)[1] - shard_range(args.batch, world, r)[0] for r in range(world)]
+    else:
+        sizes_all = [B] * world
+    # receive buffers of the per-step gather are allocated once, outside the timed loop
+    gather_bufs = None
+    if use_dist:
+        from safe_mpc_amd.sharding import gather_buffers
+        gather_bufs = gather_buffers(gather_in, sizes_all, rank)
 
     def sub_step(sb, first):
         """One closed-loop step of one sub-batch, entirely on its stream, state updated in place (graph-capturable)."""
@@ -210,7 +298,7 @@ def main():
                 off += sb.n
             for sb in subs:
                 sb.stream.wait_stream(cur)
-            gather_to_root(gather_in, sizes=[B] * world)
+            gather_to_root(gather_in, sizes=sizes_all, bufs=gather_bufs, concat=False)
 
     def barrier():
         for sb in subs:
@@ -267,48 +355,71 @@ def main():
             ugf = torch.cat([sb.ug for sb in subs]); pf = torch.cat([sb.p for sb in subs])
         torch.cuda.synchronize()
         sv.enable_timing(True)
-        acc = np.zeros(6)
-        probes = 5
+        acc = np.zeros(8)
+        probes, it_probe = 5, 0.0
         for _ in range(probes):
             with torch.cuda.stream(st_):
                 sv.guess_correction(xgf, ugf)
-                sv.solve(xs, xgf, ugf, pf)
+                out_p = sv.solve(xs, xgf, ugf, pf)
             tm = sv.timing()
-            acc += [tm['time_lin'], tm['time_nn'], tm['time_qp'], tm['time_tot'], tm['time_qp_setup'], tm['time_qp_ipm']]
+            it_probe += float(out_p[3].double().mean().item())
+            acc += [tm['time_lin'], tm['time_nn'], tm['time_qp'], tm['time_tot'], tm['time_qp_setup'], tm['time_qp_ipm'],
+                    tm['qp_wave_busy_mean'], tm['qp_wave_span']]
         acc /= probes
+        it_probe /= probes
         alg = algorithmic_bytes(prob.nq, N) * B
         ach = alg / acc[5] / 1e9
-        # HBM bytes per launch from the committed PMC passes of the same kernel / workload (profiles/, scripts/pmc_traffic.py);
-        # counters cannot be read from inside this process
-        traffic, traffic_rate = None, None
-        tf = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(tf) and B == B_PER_GPU:
-            tj = json.load(open(tf))
-            traffic = tj['traffic_bytes_per_launch']
-            # (same-run ratio: the PMC passes time their own launches, whose iteration counts differ from this probe's)
-            traffic_rate = tj.get('traffic_GBps_in_pmc_run')
+        # FLOP fractions: algorithmic flops of the launch / its HIP-event duration / peak
+        nh = prob.nq + prob.desc.n_rows + 1
+        qp_fl = qp_flops_per_iteration(prob.nq, N, nh) * it_probe * B
+        mlp_rows = B if prob.desc.nn_mode == 1 else (B * N if prob.desc.nn_mode == 2 else 0)
+        mlp_fl = mlp_flops_per_row(prob.nq) * mlp_rows
+        # HBM bytes per launch come from separate rocprofv3 --pmc passes over scripts/qp_bench.py (counters cannot be read from
+        # inside this process): committed file, named here; null when there is none for this round's kernel
+        traffic, traffic_rate, traffic_src = None, None, None
+        for name in ('r02_pmc_traffic.json',):
+            tf = os.path.join(ROOT, 'profiles', name)
+            if os.path.exists(tf) and B == B_PER_GPU and CONTROLLER == 'st':
+                tj = json.load(open(tf))
+                traffic, traffic_rate, traffic_src = tj['traffic_bytes_per_launch'], tj.get('traffic_GBps_in_pmc_run'), 'profiles/' + name
         roof = {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_GBps_in_pmc_run': traffic_rate,
+                'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                'traffic_GBps_in_pmc_run': traffic_rate,
+                'flop_frac_qp_fp64': qp_fl / acc[5] / 1e12 / FP64_VALU_PEAK_TF,
+                'flop_frac_mlp_mfma': (mlp_fl / acc[1] / 1e12 / MFMA_F32_PEAK_TF) if mlp_rows and acc[1] > 0 else None,
+                'flops': {'qp_per_launch': qp_fl, 'qp_TFLOPs': qp_fl / acc[5] / 1e12, 'fp64_valu_peak_TFLOPs': FP64_VALU_PEAK_TF,
+                          'mlp_per_launch': mlp_fl, 'mlp_TFLOPs': (mlp_fl / acc[1] / 1e12) if mlp_rows and acc[1] > 0 else None,
+                          'mfma_f32_peak_TFLOPs': MFMA_F32_PEAK_TF, 'mlp_rows': mlp_rows,
+                          'note': 'mlp time = features + GEMMs + chain kernels of the network pass (HIP events)'},
+                'load_balance': {'span_over_mean_busy': acc[7] / acc[6] if acc[6] > 0 else None,
+                                 'mean_instance_busy_ms': acc[6] * 1e3, 'launch_span_ms': acc[7] * 1e3,
+                                 'note': 'k_qp_ipm: first start -> last end of any half-wavefront over the mean busy time of one '
+                                         '(smpc_get_qp_wave_stats); 1.0 = no time spent waiting for the slowest instances'},
+                'mean_ipm_iterations_in_probe': it_probe,
                 'kernel_ms': {'linearise': acc[0] * 1e3, 'mlp': acc[1] * 1e3, 'qp_setup': acc[4] * 1e3, 'qp_ipm': acc[5] * 1e3,
                               'solve_total': acc[3] * 1e3},
-                'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={B}, alone on the GPU'}
+                'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={B}, alone on the GPU, closed-loop state after the timed steps'}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        nb = min(B, 2048)
-        cpu = cpu_baseline(prob, net, x0_h[:nb], xg_h[:nb], ug_h[:nb], p_h[:nb])
+        nb = min(B, 1024)
+        h = lambda a: a[:nb].cpu().numpy()
+        cpu = cpu_baseline(prob, net, h(xs), h(xgf), h(ugf), h(pf))
 
     if rank == 0:
-        total = B * world * args.steps
+        total = B_total * args.steps
         line = {
-            'metric': 'RTI-MPC instance-steps/s (batch=4096 per GPU, Z1 N=30)',
+            'metric': 'RTI-MPC instance-steps/s (batch=4096 per GPU, Z1 N=30)' if args.scaling == 'weak' else
+                      'RTI-MPC instance-steps/s (batch=4096 in total, Z1 N=30)',
             'value': total / elapsed, 'unit': 'instance-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'C1: Z1-class 6-DoF, N=30, 4096 instances/GPU, controller ' + CONTROLLER +
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'C1: Z1-class 6-DoF, N=30, {args.batch} instances' + ('/GPU' if args.scaling == 'weak' else ' in total') +
+                                   ', controller ' + CONTROLLER +
                                    (' (soft terminal NN row, ' if CONTROLLER == 'st' else ' (NN row as configured, ') +
                                    'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',
-                       'batch_per_gpu': B, 'horizon': N, 'controller': CONTROLLER, 'streams_per_gpu': S, 'hip_graphs': bool(subs[0].graph is not None),
+                       'batch_per_gpu': B, 'batch_total': B_total, 'horizon': N, 'controller': CONTROLLER, 'streams_per_gpu': S,
+                       'hip_graphs': bool(subs[0].graph is not None),
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
                        'failed_instance_steps': fails},
             'roofline': roof, 'cpu_baseline': cpu,

@@ -257,6 +257,10 @@ int smpc_get_timing(smpc_handle* h, float* ms4);
 /* Split of ms[2] of smpc_get_timing: ms2[0] = k_qp_setup (stage records + initial point), ms2[1] = k_qp_ipm (the interior-
  * point iterations) -- the per-kernel durations rocprofv3 --kernel-trace reports (acados: time_qp_solver_call). */
 int smpc_get_qp_timing(smpc_handle* h, float* ms2);
+/* Load balance of the last timed k_qp_ipm launch: out3[0] = mean busy time of a half-wavefront (= one instance), out3[1] =
+ * first start to last end of any half-wavefront, both in microseconds of the constant 100 MHz clock, out3[2] = half-waves
+ * counted.  out3[1] / out3[0] is the share of the launch spent waiting for its slowest instances. */
+int smpc_get_qp_wave_stats(smpc_handle* h, double* out3);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('SMPC_HIP_LIB') or os.path.join(_CSRC, 'libsmpc_hip.so
 SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error', 'smpc_set_mlp', 'smpc_set_horizon',
            'smpc_set_stage_bounds', 'smpc_set_slack_weights', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',
            'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_rollout_batch', 'smpc_sync', 'smpc_stream',
-           'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing']
+           'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing', 'smpc_get_qp_wave_stats']
 
 
 class EngineError(RuntimeError):
@@ -70,5 +70,6 @@ def lib():
     L.smpc_enable_timing.argtypes = [vp, C.c_int]
     L.smpc_get_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.smpc_get_qp_timing.argtypes = [vp, C.POINTER(C.c_float)]
+    L.smpc_get_qp_wave_stats.argtypes = [vp, C.POINTER(C.c_double)]
     _lib = L
     return L

@@ -62,6 +62,7 @@ struct smpc_handle {
     int timing = 0;
     int timed = 0;              // a solve has been timed since timing was enabled
     hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned long long* d_wstat = nullptr;   // [4] load-balance probe of k_qp_ipm (timing builds of a call only)
     int32_t* d_pol = nullptr;   // fails / accept counters of smpc_rollout_batch, [2][pol_B]
     int pol_B = 0;
     float last_ms[4] = {0, 0, 0, 0};
@@ -276,6 +277,13 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         order = h->d_order;
     }
     const int pairs = (int)(((long)B * (h->N + 1) + 1) / 2);
+    unsigned long long* wstat = nullptr;
+    if (h->timing) {
+        if (!h->d_wstat) HIPCHK(h, hipMalloc((void**)&h->d_wstat, 4 * sizeof(unsigned long long)));
+        const unsigned long long init[4] = {0ull, ~0ull, 0ull, 0ull};
+        HIPCHK(h, hipMemcpyAsync(h->d_wstat, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+        wstat = h->d_wstat;
+    }
     // the row counts of the shipped geometries are compile-time constants of the kernels (6: the reference's six capsule
     // pairs, config.yaml:205-216; 4: config_fr7.yaml); any other count takes the runtime-row-count instantiation
 #define SMPC_QP_LAUNCH(MR_)                                                                                                        \
@@ -284,7 +292,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
                            bhi, h->d_zl, h->d_ev, h->d_ws, bstride);                                                               \
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                           \
         hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
-                           ug, h->d_ws, xo, uo, st, it, order, h->d_last_it);                                                      \
+                           ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat);                                               \
     } while (0)
     switch (h->desc.n_rows) {
     case 6: SMPC_QP_LAUNCH(6); break;
@@ -380,6 +388,7 @@ void smpc_destroy(smpc_handle* h) {
     for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
     if (h->d_pol) (void)hipFree(h->d_pol);
     if (h->d_roll) (void)hipFree(h->d_roll);
+    if (h->d_wstat) (void)hipFree(h->d_wstat);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -829,6 +838,20 @@ int smpc_get_qp_timing(smpc_handle* h, float* ms2) {
     HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
     HIPCHK(h, hipEventElapsedTime(&ms2[0], h->ev_t[2], h->ev_t[4]));
     HIPCHK(h, hipEventElapsedTime(&ms2[1], h->ev_t[4], h->ev_t[3]));
+    return SMPC_OK;
+}
+
+int smpc_get_qp_wave_stats(smpc_handle* h, double* out3) {
+    if (!h || !out3) return SMPC_EINVAL;
+    if (!h->timing || !h->timed || !h->d_wstat) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    unsigned long long w[4];
+    HIPCHK(h, hipMemcpy(w, h->d_wstat, sizeof(w), hipMemcpyDeviceToHost));
+    const double tick_us = 1e-2;   // s_memrealtime: constant 100 MHz
+    out3[0] = w[3] ? (double)w[0] / (double)w[3] * tick_us : 0.0;   // mean busy time of a half-wave (one instance), us
+    out3[1] = w[3] ? (double)(w[2] - w[1]) * tick_us : 0.0;          // first start -> last end, us
+    out3[2] = (double)w[3];
     return SMPC_OK;
 }
 

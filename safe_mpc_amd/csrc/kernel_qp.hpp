@@ -481,10 +481,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const smpc_problem_desc* __restrict__ D, int B, int N, const double* __restrict__ x0, const double* __restrict__ xg,
     const double* __restrict__ ug, double* __restrict__ ws_all, double* __restrict__ x_out, double* __restrict__ u_out,
     int32_t* __restrict__ status, int32_t* __restrict__ qp_iter, const int32_t* __restrict__ order,
-    int32_t* __restrict__ last_iter) {
+    int32_t* __restrict__ last_iter, unsigned long long* __restrict__ wstat) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
                   LC0 = LyT::LC0, KS = LyT::KS;
+    // load-balance probe (smpc_get_qp_wave_stats): two reads of the constant 100 MHz clock per half-wave; the first one is
+    // parked in LDS (the kernel has no register to spare)
+    __shared__ unsigned long long s_tbegin[2];
+    if (wstat && (threadIdx.x & 31) == 0) s_tbegin[threadIdx.x >> 5] = __builtin_amdgcn_s_memrealtime();
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS, MRP_MAX = qp_even_c(MR_MAX);
     constexpr int NRC_MAX = NQ + MR_MAX + 1;
     static_assert(MRT < 0 || NX + NRC_MAX <= NL, "one lane per constraint row");
@@ -621,18 +625,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // ---- initial residual norm and complementarity from the setup partials -----------------------------------------------
     double R0 = 0.0, mu;
     int m_comp;
-    bool infeasible0;
     {
-        double ms = 0.0, cn = 0.0, inf0 = 0.0;
+        double ms = 0.0, cn = 0.0;
         for (int k = hl; k <= N; k += 32) {
             const double* pt = ws + (size_t)k * Ly.stride + Ly.oPART;
             R0 = fmax(R0, pt[0]);
             ms += pt[1];
             cn += pt[2];
-            inf0 = fmax(inf0, pt[3]);
         }
         R0 = half_max(R0);
-        infeasible0 = half_max(inf0) > 0.0;
         m_comp = (int)half_sum(cn);
         if (m_comp == 0) m_comp = 1;
         mu = half_sum(ms) / (double)m_comp;
@@ -1185,10 +1186,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         atomicAdd(&g_qp_prof[15], (unsigned long long)it);
     }
 #endif
+    if (wstat && hl == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime(), t_begin = s_tbegin[half];
+        atomicAdd(&wstat[0], t_end - t_begin);   // busy ticks summed over half-waves
+        atomicMin(&wstat[1], t_begin);           // first start
+        atomicMax(&wstat[2], t_end);             // last end
+        atomicAdd(&wstat[3], 1ull);
+    }
     if (hl == 0) {
         // acados' RTI tolerates a QP that stopped at its iteration cap (see oracle); breakdown / min-step are QP failures
         int stc = (st_code == 0 || st_code == 2) ? SMPC_STATUS_SUCCESS : SMPC_STATUS_QP_FAILURE;
-        if (infeasible0) stc = SMPC_STATUS_QP_FAILURE;   // a violated constant row at node 0 (rows_at_node0)
+        if (ws[Ly.oPART + 3] != 0.0) stc = SMPC_STATUS_QP_FAILURE;   // a violated constant row at node 0 (k_qp_setup, rows_at_node0)
         if (any_bad && stc == SMPC_STATUS_SUCCESS) stc = SMPC_STATUS_NAN;
         status[b] = stc;
         if (qp_iter) qp_iter[b] = it;

@@ -26,9 +26,20 @@ def shard_by_horizon(horizons, world, rank):
     return out
 
 
-def gather_to_root(local, sizes=None, dst=0):
+def gather_buffers(local, sizes, rank, dst=0):
+    """Receive buffers of :func:`gather_to_root`, allocated once by a caller that gathers every step."""
+    import torch
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    recv = [torch.empty_like(pad) for _ in sizes] if rank == dst else None
+    return pad, recv
+
+
+def gather_to_root(local, sizes=None, dst=0, bufs=None, concat=True):
     """Gather per-rank result tensors of shape [B_r, ...] on ``dst``; returns the concatenation on dst, None elsewhere.
-    Uneven shards are padded to the largest one (torch.distributed.gather needs equal shapes)."""
+    Uneven shards are padded to the largest one (torch.distributed.gather needs equal shapes).  ``bufs`` (from
+    :func:`gather_buffers`) keeps the pad / receive buffers out of the per-step path; with ``concat=False`` the root
+    gets the list of per-rank views instead of a fresh concatenation."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -37,11 +48,14 @@ def gather_to_root(local, sizes=None, dst=0):
         all_n = [torch.zeros_like(n) for _ in range(world)]
         dist.all_gather(all_n, n)
         sizes = [int(v.item()) for v in all_n]
-    m = max(sizes)
-    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
+    pad, recv = bufs if bufs is not None else gather_buffers(local, sizes, rank, dst)
+    if pad.shape[0] == local.shape[0]:
+        src = local                          # even shards: no staging copy at all
+    else:
+        pad[:local.shape[0]] = local
+        src = pad
+    dist.gather(src, recv, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+    views = [b[:s] for b, s in zip(recv, sizes)]
+    return torch.cat(views, dim=0) if concat else views

@@ -130,8 +130,11 @@ class BatchedOcpSolver:
         self._chk(self.L.smpc_get_timing(self.h, ms))
         q = (C.c_float * 2)()
         self._chk(self.L.smpc_get_qp_timing(self.h, q))
+        w = (C.c_double * 3)()
+        self._chk(self.L.smpc_get_qp_wave_stats(self.h, w))
         return {'time_lin': ms[0] * 1e-3, 'time_nn': ms[1] * 1e-3, 'time_qp': ms[2] * 1e-3, 'time_tot': ms[3] * 1e-3,
-                'time_qp_setup': q[0] * 1e-3, 'time_qp_ipm': q[1] * 1e-3}
+                'time_qp_setup': q[0] * 1e-3, 'time_qp_ipm': q[1] * 1e-3,
+                'qp_wave_busy_mean': w[0] * 1e-6, 'qp_wave_span': w[1] * 1e-6}
 
     # -- argument plumbing -----------------------------------------------------------------------------------------------
     def _prep(self, arrs, shapes, dtypes=None):

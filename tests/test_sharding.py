@@ -67,3 +67,64 @@ def test_two_rank_gloo_gather_matches_single_process():
         pr.join(timeout=60)
         assert pr.exitcode == 0
     assert got.shape == (7, 7) and np.array_equal(got, want)
+
+
+def _worker_prealloc(rank, world, port, q):
+    """the bench's per-step form: buffers allocated once (gather_buffers), two steps, no concatenation on the root."""
+    import torch
+    import torch.distributed as dist
+    from safe_mpc_amd.sharding import gather_buffers, gather_to_root
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    total = 9                                               # strong scaling: 9 instances in total over 2 ranks (5 + 4)
+    sizes = [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
+    lo, hi = shard_range(total, world, rank)
+    local = torch.zeros((hi - lo, 3), dtype=torch.float64)
+    bufs = gather_buffers(local, sizes, rank)
+    got = []
+    for step in range(2):
+        local[:] = torch.arange(lo, hi, dtype=torch.float64)[:, None] + 100.0 * step
+        views = gather_to_root(local, sizes=sizes, bufs=bufs, concat=False)
+        if rank == 0:
+            got.append(torch.cat(views).numpy().copy())
+    if rank == 0:
+        q.put(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_with_preallocated_buffers():
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_prealloc, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for step in range(2):
+        assert np.array_equal(got[step][:, 0], np.arange(9) + 100.0 * step)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` must never fall back to fewer GPUs silently: with no launcher environment it
+    spawns the ranks itself, and exits non-zero before touching a GPU when N exceeds what is visible."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(max(n + 1, 2)), '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == '' and 'refusing' in r.stderr
+    # a launcher environment that disagrees with --gpus is an error as well
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ''
