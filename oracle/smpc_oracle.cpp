@@ -546,7 +546,8 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
 
     double rho = 1.0;  // product of (1 - alpha): every linear residual equals rho * (its initial value)
     int it = 0, status = 2;
-    std::vector<std::vector<double>> gh(N + 1, std::vector<double>(MAXZ));
+    static thread_local std::vector<std::vector<double>> gh;
+    if ((int)gh.size() < N + 1) gh.assign(N + 1, std::vector<double>(MAXZ));
     double P[MAXX][MAXX], pv[MAXX];
 
     auto mu_now = [&]() {
@@ -860,11 +861,9 @@ bool build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const doub
         const smpc_node_eval& e = ev[k];
         const double* xk = xg + (size_t)k * nx;
         const double* pk = p + (size_t)k * SMPC_NP;
+        std::memset((void*)&s, 0, sizeof(Stage));   /* (workspaces are reused across instances) */
         s.nu = k < N ? nu : 0;
         int o = s.nu, nz = o + nx;
-        std::memset(s.H, 0, sizeof(s.H));
-        std::memset(s.g, 0, sizeof(s.g));
-        std::memset(s.Cm, 0, sizeof(s.Cm));
         double cs = k < N ? D.cost_scale_stage : D.cost_scale_term;
         double lm = k < N ? D.lm_stage : D.lm_term;
         if (D.cost_kind == SMPC_COST_REACH) {
@@ -1082,11 +1081,15 @@ int orc_solve_batch(void* h, int B, const double* x0, const double* xg, const do
         const double* xb = xg + (size_t)b * (N + 1) * nx;
         const double* ub = ug + (size_t)b * N * nu;
         const double* pb = p + (size_t)b * (N + 1) * SMPC_NP;
-        std::vector<smpc_node_eval> ev(N + 1);
+        /* per-thread workspaces, reused across instances: 31 stages are ~0.4 MB, which glibc serves by mmap/munmap -- with
+         * one allocation per instance the threads of a many-core host serialise on the kernel's address-space lock */
+        static thread_local std::vector<smpc_node_eval> ev;
+        static thread_local std::vector<Stage> S;
+        ev.resize(N + 1);
+        S.resize(N + 1);
         for (int k = 0; k <= N; k++)
             eval_node(D, &o->net, k, N, xb + (size_t)k * nx, k < N ? ub + (size_t)k * nu : nullptr,
                       pb + (size_t)k * SMPC_NP, &ev[k]);
-        std::vector<Stage> S(N + 1);
         double dx0[MAXX];
         const size_t boff = (size_t)b * (N + 1) * nx;
         const double* blo = o->inst_B == B ? o->lo_b.data() + boff : o->lo_st.data();

@@ -234,8 +234,8 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
     const long n1 = (long)B * (N + 1), n2 = (long)B * N;
     hipLaunchKernelGGL((k_node_geometry<NQ>), dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, s, h->d_desc, B, N, d_xg,
                        d_p, d_ev);
-    hipLaunchKernelGGL((k_node_torque<NQ>), dim3((unsigned)((n2 + 127) / 128), 3 * NQ), dim3(128), 0, s, h->d_desc, B, N,
-                       d_xg, d_ug, d_ev);
+    hipLaunchKernelGGL((k_node_torque<NQ>), dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg, d_ug,
+                       d_ev);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
     if (h->desc.nn_mode != SMPC_NN_NONE) {
