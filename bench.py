@@ -108,14 +108,33 @@ def initial_states(solver, prob, B, rank):
     return np.vstack(xs)[:B]
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands out a share of
+    its host's cores; running one thread per visible core oversubscribes the quota and gets throttled)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]                     # cgroup v2
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())                # cgroup v1
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=10.0, latency_solves=160):
     """CPU port (oracle/) on this host's cores, on a bounded sample of the closed-loop state the GPU leg was timed on:
     (1) OpenMP over instances on all cores -> instance-steps/s; (2) ONE thread, ONE instance per call -> latency p50 / p99
     (what scripts/mpc.py:300-303 prints per step for the reference's sequential loop)."""
-    from oracle.oracle import Oracle, build
+    from oracle.oracle import Oracle, build, set_num_threads
     build()
     o = Oracle(prob, (net.weights, net.biases))
-    cores = len(os.sched_getaffinity(0))
+    cores = set_num_threads(usable_cores())
     chunk, done, iters = min(len(x0), 8 * cores), 0, 0
     o.solve_batch(x0[:cores], xg[:cores], ug[:cores], p[:cores])      # warm the code path
     t0 = time.perf_counter()
@@ -126,7 +145,8 @@ def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=10.0, latency_solves=160):
         done += chunk
     dt = time.perf_counter() - t0
     lat = []
-    for i in range(latency_solves):                                    # B = 1: the OpenMP loop has one iteration = one thread
+    set_num_threads(1)                                                 # no team to wake: a plain single-threaded call
+    for i in range(latency_solves):
         j = i % len(x0)
         t1 = time.perf_counter()
         o.solve_batch(x0[j:j + 1], xg[j:j + 1], ug[j:j + 1], p[j:j + 1])

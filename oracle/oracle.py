@@ -47,6 +47,11 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def set_num_threads(n):
+    """OpenMP threads of the batch entry points; returns the number now in use."""
+    return int(lib().orc_set_num_threads(int(n)))
+
+
 class Oracle:
     """CPU restatement of the engine behind the same problem descriptor."""
 

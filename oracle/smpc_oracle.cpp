@@ -38,6 +38,9 @@
 #include <vector>
 
 #include "../include/smpc.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 namespace {
 
@@ -480,7 +483,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
            double* res_out) {
     const int nq = nu;
     const double c = 0.5 * dt * dt;
-    const double thr = 1e-1, tau_ftb = 0.995, alpha_min = 1e-12;
+    const double thr_hard = 3e-2, thr_soft = 1e-1, tau_ftb = 0.995, alpha_min = 1e-12;
 
     /* A x, A^T x, B u, B^T x for the double integrator (env_model.py:63-67) */
     auto Ax = [&](const double* x, double* y) {
@@ -500,8 +503,17 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         for (int i = 0; i < nz; i++) s.z[i] = 0.0;
         if (k == 0) for (int i = 0; i < nx; i++) s.z[s.nu + i] = dx0[i];
         for (int r = 0; r < s.nr; r++) {
-            double cz = 0.0;
-            for (int i = 0; i < nz; i++) cz += s.Cm[r][i] * s.z[i];
+            double cz = 0.0, cn = 0.0;
+            for (int i = 0; i < nz; i++) { cz += s.Cm[r][i] * s.z[i]; cn = std::max(cn, std::fabs(s.Cm[r][i])); }
+            /* Slack floor of the starting point.  A hard row starts at least thr_hard |c|_inf inside its bound: a distance to
+             * the boundary measured in the variables, not in the row's own units.  With one absolute floor (0.1, round 1) a
+             * steep row -- the safe-set row at zero velocity has |dg/dv| ~ 1e2..1e3 through the eps-regularised direction,
+             * safe_set.py:83-87 -- whose margin of "50" is really 1e-4 away from active started as if far inactive, and its
+             * multiplier was then walked down one row per iteration (7-DoF, N = 40, row on every node: 36 iterations, now
+             * 14); a flat row (squared capsule distances, |c| ~ 0.1) sitting on its bound started 0.1 = three times its
+             * own magnitude outside it (66 iterations on the degenerate 7-DoF start, now 33).  The soft row keeps the
+             * absolute floor: its slack variable is in the row's units. */
+            const double thr = s.soft[r] < 0.0 ? thr_hard * (cn > 0.0 ? cn : 1.0) : thr_soft;
             s.sl[r] = 0.0;
             if (s.has_lo[r]) {
                 double sl0 = s.soft[r] >= 0.0 ? thr : 0.0;
@@ -756,12 +768,16 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         }
     };
 
+    int blk_k = 0, blk_r = 0;   /* who blocks the step (SMPC_ORACLE_TRACE only) */
     auto max_step = [&]() {
         double a = 1e300;
-        auto lim = [&](double y, double dy) { if (dy < 0.0) a = std::min(a, -y / dy); };
+        int cur_k = 0, cur_r = 0;
+        auto lim = [&](double y, double dy) { if (dy < 0.0 && -y / dy < a) { a = -y / dy; blk_k = cur_k; blk_r = cur_r; } };
         for (int k = 0; k <= N; k++) {
             Stage& s = S[k];
+            cur_k = k;
             for (int r = 0; r < s.nr; r++) {
+                cur_r = r;
                 if (s.has_lo[r]) {
                     lim(s.tl[r], s.dtl[r]);
                     lim(s.ll[r], s.dll[r]);
@@ -829,7 +845,8 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         rho *= (1.0 - alpha);
         mu = mu_now();
         if (std::getenv("SMPC_ORACLE_TRACE"))
-            std::fprintf(stderr, "it %3d a_aff %.3e sigma %.3e alpha %.3e mu %.3e rho*R0 %.3e\n", it, a_aff, sigma, alpha, mu, rho * R0);
+            std::fprintf(stderr, "it %3d a_aff %.3e sigma %.3e alpha %.3e mu %.3e rho*R0 %.3e  blocked by stage %d row %d (tl %.2e ll %.2e tu %.2e lu %.2e)\n",
+                         it, a_aff, sigma, alpha, mu, rho * R0, blk_k, blk_r, S[blk_k].tl[blk_r], S[blk_k].ll[blk_r], S[blk_k].tu[blk_r], S[blk_k].lu[blk_r]);
         if (!(mu == mu)) { status = 4; break; }
     }
     if (it == o.max_iter && status == 2 && mu <= o.tol && rho * R0 <= o.tol) status = 0;
@@ -1007,6 +1024,17 @@ int orc_set_stage_bounds(void* h, const double* lo, const double* hi) {
     o->lo_st.assign(lo, lo + n);
     o->hi_st.assign(hi, hi + n);
     return 0;
+}
+
+/* number of OpenMP threads used by the batch entry points (bench.py's cpu_baseline: all usable cores, then 1) */
+int orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 int orc_set_slack_weights(void* h, const double* zl) {

@@ -48,7 +48,8 @@
 
 namespace smpc {
 
-constexpr double QP_THR = 1e-1;
+constexpr double QP_THR = 1e-1;        // slack floor of a soft row and of its slack variable
+constexpr double QP_THR_HARD = 3e-2;   // slack floor of a hard row per unit of its gradient's max-norm
 constexpr double QP_FTB = 0.995;
 constexpr double QP_ALPHA_MIN = 1e-12;
 constexpr double QP_ABSENT = 1e300;  // sentinel for a missing bound side inside the workspace
@@ -406,17 +407,26 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         const int r = hl;
         double tl = 1.0, ll = 0.0, tu = 1.0, lu = 0.0;
         if (r < NRT) {
-            double cz;
+            double cz, cn = 1.0;
             if (r < NX) cz = sZ0[NU + r];
             else {
                 cz = 0.0;
-                for (int c = 0; c < NZ; c++) cz = fma(sC[(r - NX) * NZP + c], sZ0[c], cz);
+                cn = 0.0;
+                for (int c = 0; c < NZ; c++) {
+                    const double cv = sC[(r - NX) * NZP + c];
+                    cz = fma(cv, sZ0[c], cz);
+                    cn = fmax(cn, fabs(cv));
+                }
             }
             const bool soft = (r == rNN) && wsoft >= 0.0;
+            // slack floor of the starting point: a hard row starts at least QP_THR_HARD |c|_inf inside its bound (a distance to
+            // the boundary measured in the variables, not in the row's units; see the oracle's qp_ipm for what steep and flat
+            // rows do under one absolute floor); the soft row keeps the absolute floor of its slack variable
+            const double thr = soft ? QP_THR : QP_THR_HARD * (cn > 0.0 ? cn : 1.0);
             if (sLO[r] > -QP_ABSENT) {
                 const double s0 = soft ? QP_THR : 0.0;
                 const double slack = cz + s0 - sLO[r];
-                tl = fmax(slack, QP_THR);
+                tl = fmax(slack, thr);
                 ll = D->qp_mu0 / tl;
                 if (soft) ll = fmin(ll, 0.5 * wsoft);
                 r0_loc = fmax(r0_loc, fabs(slack - tl));
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
             }
             if (sHI[r] < QP_ABSENT) {
                 const double slack = sHI[r] - cz;
-                tu = fmax(slack, QP_THR);
+                tu = fmax(slack, thr);
                 lu = D->qp_mu0 / tu;
                 r0_loc = fmax(r0_loc, fabs(slack - tu));
                 cnt += 1;

@@ -161,3 +161,23 @@ def test_c3_horizon_alpha_sweep_grid():
         xb, ub, sb, ib = o.solve_batch(x_all[idx], xg, ug, p)
         assert xa.shape == (B, N + 1, 12) and np.array_equal(sa, sb)
         assert np.abs(ua - ub).max() < 1e-4 * (1 + np.abs(ub).max())
+
+
+@pytest.mark.gpu
+def test_c4_degenerate_start_on_a_collision_bound():
+    """Round 1's straggler: a 7-DoF start whose constant guess sits ON the capsule-sphere bound (margin 4.7e-6) at all 40
+    nodes -- a degenerate QP (the same active row at every stage).  66 interior-point iterations in round 1, 33 with the
+    starting point scaled by the rows' gradients; engine and oracle agree on the count and on the solution."""
+    import os
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    par, prob, net = make_problem_fr7(N=40)
+    s, o = BatchedOcpSolver(prob, net), Oracle(prob, (net.weights, net.biases))
+    x0 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'c4_degenerate_start.npz'))['x0']
+    xg, ug, p = constant_guess(prob, x0, ee_ref=prob.ee_ref)
+    ev = o.eval_nodes(xg, ug, p)
+    assert 0.0 < ev[0, 1]['row_val'][0] - prob.row_lb[0] < 1e-5          # the row is (barely) satisfied at the guess
+    xa, ua, sa, ia = s.solve(x0, xg, ug, p)
+    xb, ub, sb, ib = o.solve_batch(x0, xg, ug, p)
+    assert sa[0] == 0 and sb[0] == 0
+    assert ia[0] <= 40 and abs(int(ia[0]) - int(ib[0])) <= 2
+    assert np.abs(ua - ub).max() < 1e-4 * (1 + np.abs(ub).max())
