@@ -130,127 +130,256 @@ _STATE = ('x_guess', 'u_guess', 'fails', 'current_step', 'x_viable', 'r')
 
 def _masked_step(ctrl, x, active):
     """controller.step on all rows, then roll back the rows that must not have stepped."""
-    snap = {k: getattr(ctrl, k).copy() for k in _STATE if hasattr(ctrl, k)}
+    xp = ctrl.xp
+    snap = {k: xp.copy(getattr(ctrl, k)) for k in _STATE if hasattr(ctrl, k)}
     u, abort = ctrl.step(x)
     for k, v in snap.items():
         cur = getattr(ctrl, k)
         m = active.reshape((-1,) + (1,) * (cur.ndim - 1))
-        setattr(ctrl, k, np.where(m, cur, v))
+        setattr(ctrl, k, xp.where(m, cur, v))
     return u, abort & active
 
 
-def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, make_controller=None, make_backup=None,
-            n_steps=None, callback=False):
-    """scripts/mpc.py:102-317 for all instances at once.  Returns the result dict the reference pickles (mpc.py:307-315)."""
+def _group_loop(params, cont_name, x_guess, u_guess, noise, control_noise, ctrl, backup, n_steps, first, callback, out):
+    """Generator running the closed loop of ONE group of instances (global indices first .. first + B); yields once per step
+    at the point where the host needs the step's single scalar from the device, so that the caller can enqueue the other
+    groups' work in the meantime (run_mpc).  Fills ``out`` with the group's result pieces when exhausted."""
     B = x_guess.shape[0]
-    n_steps = int(n_steps if n_steps is not None else params.n_steps)
-    make_controller = make_controller or (lambda name, batch: get_controller(name, params, batch))
-    make_backup = make_backup or (lambda batch: SafeBackupController(params, batch))
-    ctrl = make_controller(cont_name, B)
-    backup = make_backup(B)
+    xp = ctrl.xp
     pr, nq, nx, nu = ctrl.problem, ctrl.nq, ctrl.nx, ctrl.nu
     kp, kd = 1.0, 1e2                                                               # mpc.py:97
     Nb = backup.N
+    solver = ctrl.ocp_solver
 
-    joints_noisy = perturbed_joint_tables(params, nq, noise, np.arange(B)) if noise > 0 else None   # mpc.py:106-107
+    seeds = np.arange(first, first + B)
+    joints_noisy = perturbed_joint_tables(params, nq, noise, seeds) if noise > 0 else None          # mpc.py:106-107
     # model.reset_seed(i) is called at EVERY step (mpc.py:126): each instance sees the same torque-noise draw each step
     tau_noise = None
     if control_noise > 0:
-        tau_noise = np.stack([np.random.default_rng(i).normal(np.zeros(nu), pr.tau_max * control_noise / 100, nu)
-                              for i in range(B)])
+        tau_noise = np.stack([np.random.default_rng(int(i)).normal(np.zeros(nu), pr.tau_max * control_noise / 100, nu)
+                              for i in seeds])
+    if xp.on_device:
+        if joints_noisy is not None:          # [B, nq] smpc_joint records as a float64 tensor (33 doubles each)
+            joints_noisy = xp.asarray(np.ascontiguousarray(joints_noisy).view(np.float64).reshape(B, nq, -1), xp.f64)
+        if tau_noise is not None:
+            tau_noise = xp.asarray(tau_noise, xp.f64)
+    x_min, x_max = xp.asarray(pr.x_min, xp.f64), xp.asarray(pr.x_max, xp.f64)
 
-    x_sim = np.full((B, n_steps + 1, nx), np.nan)
-    u_log = np.full((B, n_steps, nu), np.nan)
-    x_sim[:, 0] = x_guess[:, 0]
+    # step-major logs (one contiguous [B, .] slab per step); transposed to the reference's [B, step, .] at the end
+    nan = float('nan')
+    x_log = xp.full((n_steps + 1, B, nx), nan)
+    u_log = xp.full((n_steps, B, nu), nan)
+    r_log = xp.full((n_steps, B), -1, xp.i64)
+    x_cur = xp.asarray(x_guess[:, 0], xp.f64)
+    x_log[0] = x_cur
     ctrl.setGuess(x_guess, u_guess)                                                  # mpc.py:119-120
     ctrl.reset_controller()
-    alive = np.ones(B, bool)
-    sa = np.zeros(B, bool)
-    ja = np.zeros(B, np.int64)
-    x_abort = np.zeros((B, Nb + 1, nx))
-    u_abort = np.zeros((B, Nb, nu))
-    collisions, viable, x_viable_log = set(), set(), []
-    x_cur = x_sim[:, 0].copy()
-    r_log = np.full((B, n_steps, 1), -1, np.int64)
+    alive = xp.full((B,), True, xp.bool_)
+    sa = xp.full((B,), False, xp.bool_)
+    ja = xp.zeros((B,), xp.i64)
+    x_abort = xp.zeros((B, Nb + 1, nx))
+    u_abort = xp.zeros((B, Nb, nu))
+    collided = xp.full((B,), False, xp.bool_)
+    viable = xp.full((B,), False, xp.bool_)
+    x_viable_log = []
+    zeros_u = xp.zeros((B, nu))
+    # last valid row of the state / input logs of every instance (mpc.py:114 pre-fills with NaN, :240-264 and :186-190 break)
+    last_x, last_u = xp.full((B,), n_steps, xp.i64), xp.full((B,), n_steps - 1, xp.i64)
+    ever_aborted = False
 
     for j in range(n_steps):
-        u = np.zeros((B, nu))
         # --- instances following their safe-abort trajectory (mpc.py:130-146)
-        in_abort = sa & alive
-        follow = in_abort & (ja < Nb)
-        if follow.any():
-            idx = np.minimum(ja, Nb - 1)
-            xa = x_abort[np.arange(B), idx]
-            ua = u_abort[np.arange(B), idx]
+        if ever_aborted:
+            in_abort = sa & alive
+            follow = in_abort & (ja < Nb)
+            idx = xp.clip_max(ja, Nb - 1)
+            xa = xp.take_rows(x_abort, idx)
+            ua = xp.take_rows(u_abort, idx)
             u_f = ua - (kp * (x_cur[:, :nq] - xa[:, :nq]) + kd * (x_cur[:, nq:] - xa[:, nq:]))
-            u = np.where(follow[:, None], u_f, u)
-        hold = in_abort & (ja >= Nb)
-        resume = hold & np.all(x_cur[:, nq:] < 5e-3, axis=1)                        # mpc.py:138
-        still = hold & ~resume
-        if still.any():
+            u = xp.where(follow[:, None], u_f, zeros_u)
+            hold = in_abort & (ja >= Nb)
+            resume = hold & xp.all_tail(x_cur[:, nq:] < 5e-3)                         # mpc.py:138
+            still = hold & ~resume
             xe = x_abort[:, -1]
             u_h = -(kp * (x_cur[:, :nq] - xe[:, :nq]) + 3e2 * (x_cur[:, nq:] - xe[:, nq:]))
-            u = np.where(still[:, None], u_h, u)
-        sa = sa & ~resume
-        ja = ja + in_abort
+            u = xp.where(still[:, None], u_h, u)
+            sa = sa & ~resume
+            ja = ja + xp.cast(in_abort, xp.i64)
+        else:
+            u = zeros_u
         # --- instances under MPC (mpc.py:151)
         stepping = alive & ~sa
-        if stepping.any():
-            if hasattr(ctrl, 'r'):
-                r_log[:, j, 0] = np.where(stepping, ctrl.r, -1)
+        if hasattr(ctrl, 'r'):
+            r_log[j] = xp.where(stepping, ctrl.r, r_log[j])
+        # (until the first abort event every live instance steps: no snapshot / roll-back needed; dead instances are never
+        #  read again, so they may step along)
+        if ever_aborted:
             u_m, ab = _masked_step(ctrl, x_cur, stepping)
-            u = np.where(stepping[:, None], u_m, u)
-            new_abort = ab & stepping
-            if new_abort.any():                                                     # mpc.py:161-190
-                xv = ctrl.getLastViableState()
-                backup.setGuess(np.repeat(xv[:, None, :], Nb + 1, axis=1), np.zeros((B, Nb, nu)))
-                st_b = backup.solve(xv)
-                failed = new_abort & (st_b != 0)
-                okb = new_abort & (st_b == 0)
-                for i in np.where(new_abort)[0]:
-                    x_viable_log.append(xv[i].copy())
-                for i in np.where(failed)[0]:
-                    collisions.add(int(i))
-                alive &= ~failed
-                x_abort = np.where(okb[:, None, None], backup.x_temp, x_abort)
-                u_abort = np.where(okb[:, None, None], backup.u_temp, u_abort)
-                ja = np.where(okb, 0, ja)
-                sa = sa | okb
-                for i in np.where(okb)[0]:
-                    viable.add(int(i))
-        # --- plant (mpc.py:240, env_model.py:192-206)
-        u_log[:, j] = np.where(alive[:, None], u, np.nan)
-        x_next, _ = ctrl.ocp_solver.plant_step(x_cur, np.where(alive[:, None], u, 0.0), joints_noisy, tau_noise)
-        # --- outcome tests on the new state (mpc.py:246-264)
-        tol = params.tol_x
-        in_box = np.all((x_next >= pr.x_min - tol) & (x_next <= pr.x_max + tol), axis=1)
-        free = np.asarray(ctrl.ocp_solver.check_trajectory(x_next[:, None, :], tol_x=1e30))
-        bad = alive & ~(in_box & free)
-        x_sim[:, j + 1] = np.where(alive[:, None], x_next, np.nan)
-        for i in np.where(bad)[0]:
-            collisions.add(int(i))
-        alive &= ~bad
-        x_cur = np.where(alive[:, None], x_next, x_cur)
+        else:
+            u_m, ab = ctrl.step(x_cur)
+        u = xp.where(stepping[:, None], u_m, u)
+        new_abort = ab & stepping
+        yield j                                   # everything up to here is enqueued; the caller serves the other groups
+        if ctrl.can_abort and xp.any(new_abort):                                     # mpc.py:161-190 (the step's one host sync)
+            ever_aborted = True
+            # the backup OCP is solved for the aborting instances only (a compact batch), from their viable states
+            rows = np.where(xp.host(new_abort))[0]
+            xv = ctrl.getLastViableState()
+            rows_b = xp.asarray(rows, xp.i64)
+            xv_c = xv[rows_b]
+            n_c = len(rows)
+            xg_c = xp.repeat_nodes(xv_c, Nb + 1)
+            xo_c, uo_c, st_c, _ = backup.ocp_solver.solve(xv_c if xp.on_device else np.ascontiguousarray(xv_c), xg_c,
+                                                          xp.zeros((n_c, Nb, nu)), backup.p[:n_c])
+            x_viable_log.append((rows + first, np.full(n_c, j), xp.host(xv_c)))
+            ok_c = st_c == 0 if xp.on_device else np.asarray(st_c) == 0
+            failed = xp.full((B,), False, xp.bool_)
+            okb = xp.full((B,), False, xp.bool_)
+            failed[rows_b] = ~ok_c
+            okb[rows_b] = ok_c
+            xa_new, ua_new = xp.copy(x_abort), xp.copy(u_abort)
+            xa_new[rows_b] = xo_c if xp.on_device else np.asarray(xo_c)
+            ua_new[rows_b] = uo_c if xp.on_device else np.asarray(uo_c)
+            collided = collided | failed
+            alive = alive & ~failed
+            jj = xp.full((B,), j, xp.i64)
+            last_x, last_u = xp.where(failed, jj, last_x), xp.where(failed, jj, last_u)   # mpc.py:186-190: u[j] is set, x[j+1] never
+            x_abort = xp.where(okb[:, None, None], xa_new, x_abort)
+            u_abort = xp.where(okb[:, None, None], ua_new, u_abort)
+            ja = ja * xp.cast(~okb, xp.i64)
+            sa = sa | okb
+            viable = viable | okb
+        # --- plant (mpc.py:240, env_model.py:192-206).  Logs are written unmasked; rows of an instance after its failure are
+        # blanked at the end from the step it died at (mpc.py:114 pre-fills them with NaN)
+        u_log[j] = u
+        x_next, _ = solver.plant_step(x_cur, u, joints_noisy, tau_noise)
+        # --- outcome tests on the new state (mpc.py:246-264): one node per instance, so the engine's box + collision test
+        # (model bounds widened by tol_x, rows against the check bounds) is exactly checkStateConstraints
+        okn = solver.check_trajectory(x_next[:, None, :] if not xp.on_device else x_next[:, None, :].contiguous())
+        okn = (okn != 0) if xp.on_device else np.asarray(okn)
+        x_log[j + 1] = x_next
+        bad = alive & ~okn
+        jj = xp.full((B,), j, xp.i64)
+        last_x, last_u = xp.where(bad, jj + 1, last_x), xp.where(bad, jj, last_u)   # the failing state j+1 stays in the log
+        collided = collided | bad
+        alive = alive & ~bad
+        x_cur = xp.where(alive[:, None], x_next, x_cur)
         if callback and j % 50 == 0:
-            print(f'step {j}: alive {alive.sum()}/{B}, in abort {int((sa & alive).sum())}, failures {len(collisions)}')
-        if not alive.any():
+            print(f'step {j} (instances {first}..{first + B - 1}): alive {int(xp.host(alive).sum())}/{B}, '
+                  f'in abort {int(xp.host(sa & alive).sum())}, failures {int(xp.host(collided).sum())}')
+        if not xp.on_device and not alive.any():
             break
-
+    if xp.on_device:
+        solver.sync()
     # convergence at the last step (mpc.py:273): the reference tests x_sim[-1], NaN for instances that broke
-    ev = ctrl.ocp_solver.eval_nodes(np.repeat(np.nan_to_num(x_sim[:, -1])[:, None, :], ctrl.N + 1, 1),
-                                    np.zeros((B, ctrl.N, nu)), ctrl.p)
-    ee = ev['ee'][:, 0, :]
-    conv_mask = alive & ~np.isnan(x_sim[:, -1]).any(1) & (np.linalg.norm(ee - pr.ee_ref, axis=1) < params.tol_conv)
-    conv_idx = np.where(conv_mask)[0].tolist()
-    viable -= set(conv_idx)
-    viable_idx = sorted(i for i in viable if i not in collisions)
-    coll_idx = sorted(collisions)
-    unconv_idx = sorted(set(range(B)) - set(conv_idx) - set(coll_idx) - set(viable_idx))
+    x_last = x_log[n_steps]
+    ev = solver.eval_nodes(xp.repeat_nodes(xp.nan_to_num(x_last), ctrl.N + 1), xp.zeros((B, ctrl.N, nu)), ctrl.p)
+    ee = xp.host(ev['ee'])[:, 0, :]
+    x_sim = np.ascontiguousarray(np.transpose(xp.host(x_log), (1, 0, 2)))
+    u_sim = np.ascontiguousarray(np.transpose(xp.host(u_log), (1, 0, 2)))
+    steps = np.arange(n_steps + 1)[None, :]
+    x_sim[steps > xp.host(last_x)[:, None]] = np.nan
+    u_sim[steps[:, :n_steps] > xp.host(last_u)[:, None]] = np.nan
+    conv = xp.host(alive) & ~np.isnan(x_sim[:, -1]).any(1) & (np.linalg.norm(ee - pr.ee_ref, axis=1) < params.tol_conv)
+    out.update(x=x_sim, u=u_sim,
+               r_receding=np.transpose(xp.host(r_log), (1, 0))[:, :, None], conv=conv, collided=xp.host(collided),
+               viable=xp.host(viable), abort_events=x_viable_log)
+
+
+def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, make_controller=None, make_backup=None,
+            n_steps=None, callback=False, on_device=False, device=0, timing=None, groups=None):
+    """scripts/mpc.py:102-317 for all instances at once.  Returns the result dict the reference pickles (mpc.py:307-315).
+
+    ``on_device=True``: the whole loop state -- the policy automaton of the controller, the safe-abort automaton of the driver
+    (flags, abort clocks, backup trajectories, PD tracking), trajectories and outcome masks -- lives in HBM as torch tensors
+    and every engine call takes the device-pointer path.  The only host synchronisation inside a step is one scalar per
+    group for the policies that can abort: "did any instance raise abort in this step?" (the backup OCP is solved only then,
+    as in the reference, mpc.py:161-190, and only for the aborting instances).  The instances are split into ``groups``
+    independent sub-batches (default 3 on the device), each with its own engine handle and HIP stream, advanced in turn:
+    while the host waits for one group's flag the others' kernels keep the GPU busy, and the long tail of one group's QP
+    launch overlaps the bulk of another's.  ``timing``: optional dict that receives wall-clock ms per step of the loop."""
+    import time
+    B = x_guess.shape[0]
+    n_steps = int(n_steps if n_steps is not None else params.n_steps)
+    if on_device:
+        make_controller = make_controller or (lambda name, batch: get_controller(name, params, batch, device=device, device_state=True))
+        make_backup = make_backup or (lambda batch: SafeBackupController(params, batch, device=device, device_state=True))
+    else:
+        make_controller = make_controller or (lambda name, batch: get_controller(name, params, batch))
+        make_backup = make_backup or (lambda batch: SafeBackupController(params, batch))
+    if groups is None:
+        groups = max(1, min(3, B // 512)) if on_device else 1
+    from .sharding import shard_range
+    spans = [shard_range(B, groups, g) for g in range(groups)]
+    gens, outs, streams = [], [], []
+    for lo, hi in spans:
+        ctrl = make_controller(cont_name, hi - lo)
+        backup = make_backup(hi - lo)
+        out = {}
+        outs.append(out)
+        gens.append(_group_loop(params, cont_name, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo,
+                                callback, out))
+        if on_device:
+            import torch
+            sv = ctrl.ocp_solver
+            streams.append(torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=torch.device('cuda', sv.device)))
+        else:
+            streams.append(None)
+
+    def advance(g):
+        """runs group g up to its next yield (end of the enqueue phase of a step); False once the group is finished"""
+        try:
+            if streams[g] is not None:
+                import torch
+                with torch.cuda.stream(streams[g]):      # torch ops and engine calls of a group share the handle's stream
+                    next(gens[g])
+            else:
+                next(gens[g])
+            return True
+        except StopIteration:
+            return False
+
+    live = [True] * groups
+    t_loop, j_loop, j = time.perf_counter(), 0, 0
+    warm = min(4, n_steps // 2)
+    while any(live):
+        for g in range(groups):
+            if live[g]:
+                live[g] = advance(g)
+        j += 1
+        if timing is not None and j == warm + 1:          # the first steps allocate workspaces: time the rest
+            if on_device:
+                import torch
+                torch.cuda.synchronize()
+            t_loop, j_loop = time.perf_counter(), j
+    if timing is not None:
+        done = max(n_steps + 1 - j_loop, 1)
+        timing['ms_per_step'] = 1e3 * (time.perf_counter() - t_loop) / done
+        timing['steps'], timing['groups'] = done, groups
+
+    # merge the groups (global instance indices)
+    x_sim = np.concatenate([o['x'] for o in outs], axis=0)
+    conv = np.concatenate([o['conv'] for o in outs])
+    collided = np.concatenate([o['collided'] for o in outs])
+    viable = np.concatenate([o['viable'] for o in outs])
+    conv_idx = np.where(conv)[0].tolist()
+    coll_idx = np.where(collided)[0].tolist()
+    cs, ks = set(conv_idx), set(coll_idx)
+    viable_idx = [int(i) for i in np.where(viable)[0] if i not in cs and i not in ks]
+    unconv_idx = sorted(set(range(B)) - cs - ks - set(viable_idx))
+    # x_viable: one row per abort event, in the order the reference's loops produce them (instance-major, then time: mpc.py:102,125)
+    ev = [e for o in outs for e in o['abort_events']]
+    if ev:
+        inst, step, xv = np.concatenate([e[0] for e in ev]), np.concatenate([e[1] for e in ev]), np.concatenate([e[2] for e in ev])
+        x_viable = xv[np.lexsort((step, inst))]
+    else:
+        x_viable = np.zeros((0, x_sim.shape[2]))
     # 'r': the reference allocates r_index as NaN and never writes it (mpc.py:116, 281) -- kept NaN for format parity; the
     # receding index actually used at every step is returned next to it as 'r_receding' (-1 where the policy has none)
-    return {'x': x_sim, 'u': u_log, 'r': np.full((B, n_steps, 1), np.nan), 'r_receding': r_log, 'conv_idx': conv_idx,
-            'collisions_idx': coll_idx, 'unconv_idx': unconv_idx, 'viable_idx': viable_idx,
-            'x_viable': np.asarray(x_viable_log)}
+    return {'x': x_sim, 'u': np.concatenate([o['u'] for o in outs], axis=0),
+            'r': np.full((B, n_steps, 1), np.nan), 'r_receding': np.concatenate([o['r_receding'] for o in outs], axis=0),
+            'conv_idx': conv_idx, 'collisions_idx': coll_idx, 'unconv_idx': unconv_idx, 'viable_idx': viable_idx,
+            'x_viable': x_viable}
 
 
 def save_pickle(path, obj):

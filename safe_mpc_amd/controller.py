@@ -14,16 +14,22 @@ from __future__ import annotations
 
 import numpy as np
 
+from ._xp import NumpyOps, TorchOps
 from .problem import OcpProblem
 from .safe_set import SafeSetNet
 
 
 class AbstractController:
+    """``device_state=True`` keeps every per-instance array of the policy (guesses, counters, receding indices, viable states,
+    per-node parameters) as ROCm torch tensors and drives the engine through its device-pointer path: ``step`` then enqueues
+    kernels only -- no array crosses PCIe and nothing synchronises with the host.  The default (numpy) is the host path."""
     cont_name = 'naive'
+    can_abort = False            # policies whose step() may return abort=True (the driver then needs one flag per step)
 
-    def __init__(self, params, batch, cost='ext', N=None, solver=None, net=None, device=0):
+    def __init__(self, params, batch, cost='ext', N=None, solver=None, net=None, device=0, device_state=False):
         self.params = params
         self.B = int(batch)
+        self.xp = TorchOps(device) if device_state else NumpyOps()
         self.problem = OcpProblem(params, self.cont_name, cost, N=N)
         self.model = self.problem                      # x_min/x_max/tau_max/ee_ref live here (AdamModel's role)
         self.N = self.problem.N
@@ -38,42 +44,44 @@ class AbstractController:
             solver = BatchedOcpSolver(self.problem, net, device=device)
         self.ocp_solver = solver
         self.time_fields = ['time_lin', 'time_sim', 'time_qp', 'time_qp_solver_call', 'time_glob', 'time_reg', 'time_tot']
-        # per-node parameters p = [ee_ref(3), alpha, flag] (controller.py:27-37, 153-156)
-        self.p = np.zeros((self.B, self.N + 1, 5))
+        xp = self.xp
+        self._x_min, self._x_max = xp.asarray(self.problem.x_min, xp.f64), xp.asarray(self.problem.x_max, xp.f64)
+        self._tau_min, self._tau_max = xp.asarray(self.problem.tau_min, xp.f64), xp.asarray(self.problem.tau_max, xp.f64)
         self._alloc()
         self.reset_controller()
 
     # -- state --------------------------------------------------------------------------------------------------------
     def _alloc(self):
-        B, N = self.B, self.N
-        self.x_guess = np.zeros((B, N + 1, self.nx))
-        self.u_guess = np.zeros((B, N, self.nu))
-        self.x_temp, self.u_temp = self.x_guess.copy(), self.u_guess.copy()
-        self.p = np.zeros((B, N + 1, 5))
-        self.p[:, :, :3] = self.problem.ee_ref
+        B, N, xp = self.B, self.N, self.xp
+        self.x_guess = xp.zeros((B, N + 1, self.nx))
+        self.u_guess = xp.zeros((B, N, self.nu))
+        self.x_temp, self.u_temp = xp.copy(self.x_guess), xp.copy(self.u_guess)
+        # per-node parameters p = [ee_ref(3), alpha, flag] (controller.py:27-37, 153-156)
+        self.p = xp.zeros((B, N + 1, 5))
+        self.p[:, :, :3] = xp.asarray(self.problem.ee_ref, xp.f64)
         self.p[:, :, 3] = self.params.alpha
         self.p[:, :, 4] = 1.0
-        self.last_status = np.full(B, 4, np.int32)                 # controller.py:125
-        self.qp_iter = np.zeros(B, np.int32)
-        self.x_viable = np.zeros((B, self.nx))
+        self.last_status = xp.full((B,), 4, xp.i32)                # controller.py:125
+        self.qp_iter = xp.zeros((B,), xp.i32)
+        self.x_viable = xp.zeros((B, self.nx))
 
     def reset_controller(self):
-        self.fails = np.zeros(self.B, np.int64)
-        self.current_step = np.zeros(self.B, np.int64)
+        self.fails = self.xp.zeros((self.B,), self.xp.i64)
+        self.current_step = self.xp.zeros((self.B,), self.xp.i64)
 
     def setReference(self, ee_ref):
         self.problem.ee_ref = np.asarray(ee_ref, float)
-        self.p[:, :, :3] = self.problem.ee_ref
+        self.p[:, :, :3] = self.xp.asarray(self.problem.ee_ref, self.xp.f64)
 
     def setGuess(self, x_guess, u_guess):
-        self.x_guess = np.array(x_guess, float, copy=True)
-        self.u_guess = np.array(u_guess, float, copy=True)
+        self.x_guess = self.xp.asarray(x_guess, self.xp.f64)
+        self.u_guess = self.xp.asarray(u_guess, self.xp.f64)
 
     def getGuess(self):
-        return np.copy(self.x_guess), np.copy(self.u_guess)
+        return self.xp.copy(self.x_guess), self.xp.copy(self.u_guess)
 
     def getLastViableState(self):
-        return np.copy(self.x_viable)
+        return self.xp.copy(self.x_viable)
 
     def getTime(self):
         try:
@@ -94,10 +102,15 @@ class AbstractController:
     def solve(self, x0):
         """controller.py:136-167 for all instances: returns status[B]; x_temp / u_temp hold the iterate regardless."""
         self.p[:, :, 3] = self.params.alpha
-        x, u, st, it = self.ocp_solver.solve(np.asarray(x0, float), self.x_guess, self.u_guess, self.p)
-        self.x_temp, self.u_temp = np.asarray(x), np.asarray(u)
-        self.last_status = np.asarray(st).copy()
-        self.qp_iter = np.asarray(it).copy()
+        if not self.xp.on_device:
+            x0 = np.asarray(x0, float)
+        x, u, st, it = self.ocp_solver.solve(x0, self.x_guess, self.u_guess, self.p)
+        if self.xp.on_device:
+            self.x_temp, self.u_temp, self.last_status, self.qp_iter = x, u, st, it
+        else:
+            self.x_temp, self.u_temp = np.asarray(x), np.asarray(u)
+            self.last_status = np.asarray(st).copy()
+            self.qp_iter = np.asarray(it).copy()
         return self.last_status
 
     def guessCorrection(self):
@@ -105,51 +118,66 @@ class AbstractController:
 
     def provideControl(self, active=None):
         """controller.py:169-184.  ``active`` masks out instances that returned early (abort)."""
-        accept = (self.fails == 0).astype(np.int32)
+        xp = self.xp
+        accept = xp.cast(self.fails == 0, xp.i32)
+        keep = active is not None
+        # the engine's device path shifts the guess in place: keep the old one for the instances that must not shift
+        old_xg = xp.copy(self.x_guess) if keep and xp.on_device else self.x_guess
+        old_ug = xp.copy(self.u_guess) if keep and xp.on_device else self.u_guess
         xg, ug, u = self.ocp_solver.provide_control(accept, self.x_temp, self.u_temp, self.x_guess, self.u_guess)
-        if active is None:
+        if not keep:
             self.x_guess, self.u_guess = xg, ug
         else:
-            u = np.where(active[:, None], u, self.u_guess[:, 0])
-            self.x_guess = np.where(active[:, None, None], xg, self.x_guess)
-            self.u_guess = np.where(active[:, None, None], ug, self.u_guess)
-        return u, np.zeros(self.B, bool)
+            u = xp.where(active[:, None], u, old_ug[:, 0])
+            self.x_guess = xp.where(active[:, None, None], xg, old_xg)
+            self.u_guess = xp.where(active[:, None, None], ug, old_ug)
+        return u, xp.zeros((self.B,), xp.bool_)
 
     # -- feasibility predicates (env_model.py:170-243, safe_set.py:61-68) ------------------------------------------------
+    def _as_state(self, x):
+        if not self.xp.on_device:
+            x = np.asarray(x, float)
+        return x[:, None, :] if x.ndim == 2 else x
+
     def checkStateConstraints(self, x):
         """env_model.py:170-173.  Reference quirk kept by default (``params.reference_quirks``):
         ``checkCollision`` returns inside its loop after the FIRST row (env_model.py:238-243), so a trajectory is
         collision-checked at its first node only, while the box test covers every node."""
-        x = np.asarray(x, float)
-        if x.ndim == 2:
-            x = x[:, None, :]
+        xp = self.xp
+        x = self._as_state(x)
         tol = self.params.tol_x
-        in_box = np.all((x >= self.problem.x_min - tol) & (x <= self.problem.x_max + tol), axis=(1, 2))
+        in_box = xp.all_tail((x >= self._x_min - tol) & (x <= self._x_max + tol))
         xc = x[:, :1] if getattr(self.params, 'reference_quirks', True) else x
-        free = np.asarray(self.ocp_solver.check_trajectory(np.ascontiguousarray(xc), tol_x=1e30))
+        if xp.on_device:
+            xc = xc.contiguous()
+            free = self.ocp_solver.check_trajectory(xc, tol_x=1e30) != 0
+        else:
+            free = np.asarray(self.ocp_solver.check_trajectory(np.ascontiguousarray(xc), tol_x=1e30))
         return in_box & free
 
     def checkSafeConstraints(self, x):
         """x[B, n_nodes, nx] (or [B, nx]) -> bool per (instance, node)."""
-        x = np.asarray(x, float)
         squeeze = x.ndim == 2
-        if squeeze:
-            x = x[:, None, :]
-        _, nn = self.ocp_solver.check_trajectory(x, want_nn=True)
-        nn = np.asarray(nn)
+        x = self._as_state(x)
+        if self.xp.on_device:
+            _, nn = self.ocp_solver.check_trajectory(x.contiguous(), want_nn=True)
+            nn = nn != 0
+        else:
+            _, nn = self.ocp_solver.check_trajectory(x, want_nn=True)
+            nn = np.asarray(nn)
         return nn[:, 0] if squeeze else nn
 
     def checkTorqueConstraints(self, x, u):
         ev = self.ocp_solver.eval_nodes(x, u, self.p)
         tau = ev['tau'][:, :self.N, :self.nq]
         tol = self.params.tol_tau
-        return np.all((tau >= self.problem.tau_min - tol) & (tau <= self.problem.tau_max + tol), axis=(1, 2))
+        return self.xp.all_tail((tau >= self._tau_min - tol) & (tau <= self._tau_max + tol))
 
     def checkDynamicsConstraints(self, x, u):
         """env_model.py:226-234 with the controller's own model (no torque saturation inside the rollout)."""
-        sim = self.ocp_solver.guess_correction(x, u)
+        sim = self.ocp_solver.guess_correction(self.xp.copy(x), u)       # (the device path integrates in place)
         n = u.shape[1]
-        return np.linalg.norm((x - sim).reshape(self.B, -1), axis=1) < self.params.tol_dyn * np.sqrt(n + 1)
+        return self.xp.norm_tail(x - sim) < self.params.tol_dyn * np.sqrt(n + 1)
 
     def checkGuess(self):
         return (self.checkStateConstraints(self.x_temp) & self.checkTorqueConstraints(self.x_temp, self.u_temp) &
@@ -157,14 +185,15 @@ class AbstractController:
 
     def initialize(self, x0, u0=None):
         """controller.py:260-272: trivial guess, one solve, keep it where it checks out.  Returns 1/0 per instance."""
-        x0 = np.asarray(x0, float)
-        self.x_guess = np.repeat(x0[:, None, :], self.N + 1, axis=1)
-        self.u_guess = np.zeros((self.B, self.N, self.nu)) if u0 is None else np.repeat(np.asarray(u0)[:, None, :], self.N, 1)
+        xp = self.xp
+        x0 = xp.asarray(x0, xp.f64)
+        self.x_guess = xp.repeat_nodes(x0, self.N + 1)
+        self.u_guess = xp.zeros((self.B, self.N, self.nu)) if u0 is None else xp.repeat_nodes(xp.asarray(u0, xp.f64), self.N)
         status = self.solve(x0)
         good = (status == 0) & self.checkGuess()
-        self.x_guess = np.where(good[:, None, None], self.x_temp, self.x_guess)
-        self.u_guess = np.where(good[:, None, None], self.u_temp, self.u_guess)
-        return good.astype(int)
+        self.x_guess = xp.where(good[:, None, None], self.x_temp, self.x_guess)
+        self.u_guess = xp.where(good[:, None, None], self.u_temp, self.u_guess)
+        return xp.cast(good, xp.i64)
 
     def step(self, x):
         raise NotImplementedError
@@ -177,8 +206,8 @@ class NaiveController(AbstractController):
         """controller.py:274-284"""
         self.guessCorrection()
         status = self.solve(x)
-        self.fails = np.where(status == 0, 0, self.fails + 1)
-        self.current_step += 1
+        self.fails = (self.fails + 1) * self.xp.cast(status != 0, self.xp.i64)      # 0 on success, fails + 1 otherwise
+        self.current_step = self.current_step + 1
         return self.provideControl()
 
 
@@ -192,28 +221,31 @@ class STController(NaiveController):
 
 class STWAController(STController):
     cont_name = 'stwa'
+    can_abort = True
 
     def setGuess(self, x_guess, u_guess):
         super().setGuess(x_guess, u_guess)
-        self.x_viable = self.x_guess[:, -1].copy()
+        self.x_viable = self.xp.copy(self.x_guess[:, -1])
 
     def checkGuess(self):
         return super().checkGuess() & self.checkSafeConstraints(self.x_temp[:, -1])
 
     def step(self, x):
         """controller.py:375-388"""
+        xp = self.xp
         self.guessCorrection()
         status = self.solve(x)
         ok = (status == 0) & self.checkStateConstraints(self.x_temp)
         first_fail = ~ok & (self.fails == 0)
-        self.x_viable = np.where(first_fail[:, None], self.x_guess[:, -2], self.x_viable)
+        self.x_viable = xp.where(first_fail[:, None], self.x_guess[:, -2], self.x_viable)
         abort = ~ok & (self.fails == self.N - 1)
-        u_abort = self.u_guess[:, 0].copy()
-        self.fails = np.where(ok, 0, np.where(abort, self.fails, self.fails + 1))
+        u_abort = xp.copy(self.u_guess[:, 0])
+        # ok: 0 ; abort: unchanged ; otherwise fails + 1
+        self.fails = xp.where(abort, self.fails, self.fails + 1) * xp.cast(~ok, xp.i64)
         active = ~abort
-        self.current_step += active
+        self.current_step = self.current_step + xp.cast(active, xp.i64)
         u, _ = self.provideControl(active)
-        return np.where(abort[:, None], u_abort, u), abort
+        return xp.where(abort[:, None], u_abort, u), abort
 
 
 class HTWAController(STWAController):
@@ -225,46 +257,49 @@ class RecedingController(STWAController):
 
     def reset_controller(self):
         super().reset_controller()
-        self.r = np.full(self.B, self.N, np.int64)
+        self.r = self.xp.full((self.B,), self.N, self.xp.i64)
         self.abort_flag = bool(self.params.abort_flag)
 
     def resetHorizon(self, N):
         super().resetHorizon(N)
-        self.r = np.full(self.B, self.N, np.int64)
+        self.r = self.xp.full((self.B,), self.N, self.xp.i64)
 
     def _set_flags(self):
         """controller.py:452-469: running nodes off except node r; terminal node always on."""
-        k = np.arange(self.N + 1)[None, :]
-        on = (k == self.N) | ((k == self.r[:, None]) & (self.r[:, None] < self.N))
-        on[:, 0] = True                                   # node 0 keeps the default flag (never carries the row anyway)
-        self.p[:, :, 4] = np.where(on, 1.0, -1.0)
+        xp = self.xp
+        k = xp.arange(self.N + 1)[None, :]
+        r = self.r[:, None]
+        on = (k == self.N) | ((k == r) & (r < self.N)) | (k == 0)   # node 0 keeps the default flag (never carries the row anyway)
+        self.p[:, :, 4] = xp.cast(on, xp.f64) * 2.0 - 1.0
 
     def _post_solve(self, x, status, u_abort):
+        xp = self.xp
         if self.abort_flag:
             self.r = self.r - 1
+            abort = self.r == 0
         else:
-            self.r = np.where(self.r > 0, self.r - 1, self.r)
-        abort = (self.r == 0) & self.abort_flag
-        self.x_viable = np.where(abort[:, None], self.x_guess[:, 1], self.x_viable)
-        self.r = np.where(abort, self.N, self.r)
+            self.r = self.r - xp.cast(self.r > 0, xp.i64)
+            abort = xp.zeros((self.B,), xp.bool_)
+        self.x_viable = xp.where(abort[:, None], self.x_guess[:, 1], self.x_viable)
+        self.r = self.r + xp.cast(abort, xp.i64) * self.N            # r = 0 -> N for the aborting instances
         ok = (status == 0) & self.checkStateConstraints(self.x_temp) & ~abort
         # r <- largest i-1, i in r+2..N, whose node passes the safe-set test (controller.py:491-494)
         safe = self.checkSafeConstraints(self.x_temp)                      # [B, N+1]
-        i = np.arange(self.N + 1)[None, :]
-        cand = safe & (i >= (self.r[:, None] + 2))
-        best = np.where(cand.any(1), self.N - np.argmax(cand[:, ::-1], axis=1), -1)   # largest such i
-        self.r = np.where(ok & (best >= 0), best - 1, self.r)
-        self.fails = np.where(abort, self.fails, np.where(ok, 0, self.fails + 1))
+        i = xp.arange(self.N + 1)[None, :]
+        best = xp.last_true(safe & (i >= (self.r[:, None] + 2)))           # largest such i, -1 if none
+        self.r = xp.where(ok & (best >= 0), best - 1, self.r)
+        # abort: unchanged ; ok: 0 ; otherwise fails + 1
+        self.fails = xp.where(abort, self.fails, (self.fails + 1) * xp.cast(~ok, xp.i64))
         active = ~abort
-        self.current_step += active
+        self.current_step = self.current_step + xp.cast(active, xp.i64)
         u, _ = self.provideControl(active)
-        return np.where(abort[:, None], u_abort, u), abort
+        return xp.where(abort[:, None], u_abort, u), abort
 
     def step(self, x):
         """controller.py:448-498"""
         self.guessCorrection()
         self._set_flags()
-        u_abort = self.u_guess[:, 0].copy()
+        u_abort = self.xp.copy(self.u_guess[:, 0])
         status = self.solve(x)
         return self._post_solve(x, status, u_abort)
 
@@ -276,17 +311,21 @@ class RealReceding(RecedingController):
     TUBE = 1e-3
 
     def step(self, x):
-        pr = self.problem
-        lo = np.broadcast_to(pr.x_min, (self.B, self.N + 1, self.nx)).copy()      # other nodes: the model bounds (:534-536)
-        hi = np.broadcast_to(pr.x_max, (self.B, self.N + 1, self.nx)).copy()
-        lo[:, self.N], hi[:, self.N] = pr.lbx_e, pr.ubx_e                         # terminal node keeps lbx_e / ubx_e
-        rows = np.where(self.r < self.N)[0]
-        if rows.size:
-            r = self.r[rows]
-            centre = self.x_guess[rows, r + 1]
-            lo[rows, r], hi[rows, r] = centre - self.TUBE, centre + self.TUBE
+        xp, pr, N = self.xp, self.problem, self.N
+        # other nodes: the model bounds (:534-536); the terminal node keeps lbx_e / ubx_e
+        k = xp.arange(N + 1)[None, :, None]
+        last = k == N
+        lo = xp.where(last, xp.asarray(pr.lbx_e, xp.f64)[None, None, :], self._x_min[None, None, :])
+        hi = xp.where(last, xp.asarray(pr.ubx_e, xp.f64)[None, None, :], self._x_max[None, None, :])
+        sel = self.r < N
+        centre = xp.take_rows(self.x_guess, xp.clip_max(self.r, N - 1) + 1)[:, None, :]     # x_guess[b, r_b + 1]
+        at_r = (k == self.r[:, None, None]) & sel[:, None, None]
+        lo = xp.where(at_r, centre - self.TUBE, lo + 0.0 * centre)      # (+ 0 * centre: broadcast to [B, N+1, nx])
+        hi = xp.where(at_r, centre + self.TUBE, hi + 0.0 * centre)
+        if xp.on_device:
+            lo, hi = lo.contiguous(), hi.contiguous()
         self.ocp_solver.set_instance_bounds(lo, hi)
-        u_abort = self.u_guess[:, 0].copy()
+        u_abort = xp.copy(self.u_guess[:, 0])
         status = self.solve(x)
         return self._post_solve(x, status, u_abort)
 
@@ -296,11 +335,12 @@ class ControllerSafeSetEverywhere(STController):
 
     def step(self, x):
         """controller.py:651-661"""
+        xp = self.xp
         self.guessCorrection()
         status = self.solve(x)
         ok = (status == 0) & self.checkStateConstraints(self.x_temp)
-        self.fails = np.where(ok, 0, self.fails + 1)
-        self.current_step += 1
+        self.fails = (self.fails + 1) * xp.cast(~ok, xp.i64)
+        self.current_step = self.current_step + 1
         return self.provideControl()
 
 

@@ -30,6 +30,7 @@ struct smpc_handle {
     double* d_zl = nullptr;                   // [N+1] run-time slack weights of the soft safe-set rows (cost_set), or null
     double *d_lo_b = nullptr, *d_hi_b = nullptr;  // [B][N+1][nx] per-instance bounds (RealReceding), valid for inst_B
     int inst_B = 0;
+    size_t inst_cap = 0;   // doubles allocated in d_lo_b / d_hi_b
     // network
     int nlayers = 0;
     int dims[SMPC_MAX_LAYERS + 1] = {0};
@@ -56,6 +57,8 @@ struct smpc_handle {
     // generic scratch for the caller entry points
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0;
+    double* d_chk = nullptr;    // check bounds of smpc_check_trajectory [x_min | x_max | row_lb | row_ub], uploaded on change
+    std::vector<double> chk_cache;
     char* d_roll = nullptr;     // staging of smpc_rollout_batch's host-pointer path, grown on demand
     size_t roll_bytes = 0;
     // timing
@@ -388,6 +391,7 @@ void smpc_destroy(smpc_handle* h) {
     for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
     if (h->d_pol) (void)hipFree(h->d_pol);
     if (h->d_roll) (void)hipFree(h->d_roll);
+    if (h->d_chk) (void)hipFree(h->d_chk);
     if (h->d_wstat) (void)hipFree(h->d_wstat);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -475,13 +479,16 @@ int smpc_set_instance_bounds(smpc_handle* h, int B, const double* lo, const doub
     if (B <= 0) return fail(h, SMPC_EINVAL, "bad batch size");
     const size_t n = (size_t)B * (h->N + 1) * 2 * h->desc.nq;
     int rc;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if ((rc = dev_alloc(h, &h->d_lo_b, n))) return rc;
-    if ((rc = dev_alloc(h, &h->d_hi_b, n))) return rc;
+    if (n > h->inst_cap) {   // (re)allocate only when the tube grows: a per-step caller pays two stream-ordered copies
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if ((rc = dev_alloc(h, &h->d_lo_b, n))) return rc;
+        if ((rc = dev_alloc(h, &h->d_hi_b, n))) return rc;
+        h->inst_cap = n;
+    }
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIPCHK(h, hipMemcpyAsync(h->d_lo_b, lo, n * sizeof(double), kind, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_hi_b, hi, n * sizeof(double), kind, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!on_device) HIPCHK(h, hipStreamSynchronize(h->stream));   // host buffers may be reused by the caller on return
     h->inst_B = B;
     return SMPC_OK;
 }
@@ -613,26 +620,36 @@ int smpc_check_trajectory(smpc_handle* h, int B, int n_nodes, const double* x, c
     const int nq = h->desc.nq, nx = 2 * nq, nr = h->desc.n_rows;
     hipStream_t s = h->stream;
     const size_t M = (size_t)B * n_nodes;
-    // bounds always come from the host side of the caller: small, copied into scratch
+    // (x_min / x_max / row bounds are host pointers on both paths: small, constant per caller)
     int rc;
-    const size_t small = sizeof(double) * (2 * nx + 2 * SMPC_MAX_ROWS);
     const size_t big = on_device ? 0 : sizeof(double) * M * nx + sizeof(int32_t) * (B + M) + 64;
-    if ((rc = ensure_tmp(h, small + big))) return rc;
-    double* d_min = (double*)h->d_tmp;
+    if ((rc = ensure_tmp(h, big))) return rc;
+    // The check bounds live in a small device block of their own and are uploaded only when they change: a copy from
+    // pageable host memory waits for the stream to drain, which would turn every per-step call of a device-resident loop
+    // into a host synchronisation.
+    {
+        std::vector<double> cur((size_t)2 * nx + 2 * SMPC_MAX_ROWS, 0.0);
+        memcpy(cur.data(), x_min, sizeof(double) * nx);
+        memcpy(cur.data() + nx, x_max, sizeof(double) * nx);
+        if (nr > 0) {
+            memcpy(cur.data() + 2 * nx, row_lb_chk, sizeof(double) * nr);
+            memcpy(cur.data() + 2 * nx + SMPC_MAX_ROWS, row_ub_chk, sizeof(double) * nr);
+        }
+        if (!h->d_chk) HIPCHK(h, hipMalloc((void**)&h->d_chk, cur.size() * sizeof(double)));
+        if (cur != h->chk_cache) {
+            HIPCHK(h, hipStreamSynchronize(s));
+            HIPCHK(h, hipMemcpy(h->d_chk, cur.data(), cur.size() * sizeof(double), hipMemcpyHostToDevice));
+            h->chk_cache.swap(cur);
+        }
+    }
+    double* d_min = h->d_chk;
     double* d_max = d_min + nx;
     double* d_rlb = d_max + nx;
     double* d_rub = d_rlb + SMPC_MAX_ROWS;
-    hipMemcpyKind kind = on_device ? hipMemcpyDefault : hipMemcpyHostToDevice;
-    HIPCHK(h, hipMemcpyAsync(d_min, x_min, sizeof(double) * nx, kind, s));
-    HIPCHK(h, hipMemcpyAsync(d_max, x_max, sizeof(double) * nx, kind, s));
-    if (nr > 0) {
-        HIPCHK(h, hipMemcpyAsync(d_rlb, row_lb_chk, sizeof(double) * nr, kind, s));
-        HIPCHK(h, hipMemcpyAsync(d_rub, row_ub_chk, sizeof(double) * nr, kind, s));
-    }
     const double* d_x = x;
     int32_t *d_ok = state_ok, *d_nn = nn_ok;
     if (!on_device) {
-        double* dx = d_rub + SMPC_MAX_ROWS;
+        double* dx = (double*)h->d_tmp;
         HIPCHK(h, hipMemcpyAsync(dx, x, sizeof(double) * M * nx, hipMemcpyHostToDevice, s));
         d_x = dx;
         d_ok = (int32_t*)(dx + M * nx);

@@ -26,8 +26,11 @@ def main(argv=None):
     print(gfile)
     data = pickle.load(open(gfile, 'rb'))
     x_guess, u_guess = data['xg'][:params.test_num], data['ug'][:params.test_num]
+    tm = {}
+    # all loop state in HBM (policy automaton, abort handling, logs); SMPC_HOST_STATE=1 keeps it in numpy arrays instead
     res = cl.run_mpc(params, cont_name, x_guess, u_guess, noise=args['noise'], control_noise=args['control_noise'],
-                     callback=True)
+                     callback=True, on_device=os.environ.get('SMPC_HOST_STATE', '0') != '1', timing=tm)
+    print(f"{tm['ms_per_step']:.3f} ms per closed-loop step of {x_guess.shape[0]} instances")
     n = x_guess.shape[0]
     print(f"Completed task: {len(res['conv_idx'])}\nCollisions: {len(res['collisions_idx'])}"
           f"\nViable states: {len(res['viable_idx'])}\nNot converged: {n - len(res['conv_idx']) - len(res['collisions_idx'])}")

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""ms per closed-loop step of the full policy layer with all state in HBM (run_mpc(on_device=True)): the controller's
+accept / reject / abort automaton, the driver's backup-OCP + PD abort handling, plant and outcome tests -- at the bench's
+workload size (B = 4096, Z1, N = 30), next to the plain-policy number bench.py reports.
+
+    python scripts/policy_bench.py [controller ...]      (default: st htwa receding)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                   # noqa: E402
+from safe_mpc_amd import closed_loop as cl                     # noqa: E402
+from safe_mpc_amd.solver import BatchedOcpSolver               # noqa: E402
+
+
+def main():
+    names = sys.argv[1:] or ['st', 'htwa', 'receding']
+    par, prob, net = bench.build_problem()
+    par.back_hor = 30
+    B, N, steps = int(os.environ.get('SMPC_B', '4096')), prob.N, int(os.environ.get('SMPC_STEPS', '60'))
+    s = BatchedOcpSolver(prob, net)
+    x0 = bench.initial_states(s, prob, B, 0)
+    xg = np.repeat(x0[:, None, :], N + 1, axis=1)
+    ug = np.zeros((B, N, prob.nu))
+    for name in names:
+        for dev in (True, False):
+            if not dev and os.environ.get('SMPC_HOST', '0') != '1':
+                continue
+            tm = {}
+            t0 = time.perf_counter()
+            res = cl.run_mpc(par, name, xg, ug, n_steps=steps, on_device=dev, timing=tm,
+                             groups=int(os.environ['SMPC_GROUPS']) if 'SMPC_GROUPS' in os.environ else None)
+            print(f"{name:12s} {'device' if dev else 'host  '} state: {tm['ms_per_step']:.3f} ms/step over {tm['steps']} steps "
+                  f"(B={B}, N={N}, groups {tm.get('groups')}; total {time.perf_counter() - t0:.1f} s incl. set-up) | collisions {len(res['collisions_idx'])} "
+                  f"viable {len(res['viable_idx'])} converged {len(res['conv_idx'])}", flush=True)
+
+
+if __name__ == '__main__':
+    main()

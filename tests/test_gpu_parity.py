@@ -414,3 +414,31 @@ def test_timing_before_any_solve_is_a_state_error():
     x0 = sample_instances(prob, 4, seed=0)
     s.solve(x0, *constant_guess(prob, x0))
     assert s.timing()['time_tot'] > 0
+
+
+@pytest.mark.parametrize('name', ['htwa', 'receding', 'real_receding'])
+def test_device_resident_policy_layer_equals_host_automaton(name):
+    """the policy automata (controller.py:375-388, 448-498, 524-565) and the driver's abort / backup / PD
+    loop (mpc.py:130-190) with all state in HBM (run_mpc(on_device=True)) against the same code on numpy arrays through the
+    engine's host path: same outcome lists, same abort events, same receding indices, trajectories to rounding."""
+    from safe_mpc_amd import closed_loop as cl
+    from safe_mpc_amd import controller as C
+    from safe_mpc_amd.parser import Parameters
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N, par.back_hor = 6, 6, [12, 256, 1], 10, 12
+    prob0 = C.OcpProblem(par, 'htwa', 'ext', N=10)
+    B = 40
+    x0 = sample_instances(prob0, B, seed=9, vel_scale=0.3)       # moving starts: some instances will have to abort
+    xg = np.repeat(x0[:, None, :], 11, axis=1)
+    ug = np.zeros((B, 10, 6))
+    host = cl.run_mpc(par, name, xg, ug, n_steps=30, control_noise=1.0)
+    # two pipelined groups on their own engine handles / streams: instances are independent, the split changes nothing
+    dev = cl.run_mpc(par, name, xg, ug, n_steps=30, control_noise=1.0, on_device=True, groups=2 if name != 'htwa' else 1)
+    for k in ('conv_idx', 'collisions_idx', 'unconv_idx', 'viable_idx'):
+        assert host[k] == dev[k], k
+    assert host['x_viable'].shape == dev['x_viable'].shape
+    assert np.array_equal(host['r_receding'], dev['r_receding'])
+    assert np.array_equal(np.isnan(host['x']), np.isnan(dev['x']))
+    assert np.nanmax(np.abs(host['x'] - dev['x'])) < 1e-9 and np.nanmax(np.abs(host['u'] - dev['u'])) < 1e-7
+    if host['x_viable'].size:
+        assert np.abs(host['x_viable'] - dev['x_viable']).max() < 1e-9
