@@ -85,13 +85,63 @@ def perturbed_joint_tables(params, nq, noise_pct, seeds):
 
 
 # ---- warm-start generation ----------------------------------------------------------------------------------------------------
-def generate_guess(params, cont_name, n, make_controller=None, sqp_tol=1e-6, verbose=False):
+def merit_terms(ctrl, x0, x, u):
+    """Pieces of the l1 merit function of the OCP at the iterate (x, u), per instance, from one batched linearisation
+    (``smpc_eval_nodes``): cost f, its gradient (dq, du parts) and the l1 norm of every constraint's violation -- initial
+    state, dynamics defects, state box, torque rows, collision rows, safe-set row (where the formulation has it)."""
+    pr, d = ctrl.problem, ctrl.problem.desc
+    nq, N, dt = ctrl.nq, ctrl.N, ctrl.params.dt
+    x, u = np.asarray(x, float), np.asarray(u, float)
+    ev = ctrl.ocp_solver.eval_nodes(x, u, ctrl.p)
+    ee = np.asarray(ev['ee'])
+    cs = np.full(N + 1, d.cost_scale_stage)
+    cs[N] = d.cost_scale_term
+    if d.cost_kind != 0:
+        err = np.sum((ee - ctrl.p[:, :, :3]) ** 2, axis=2)                           # [B, N+1]
+        f = (cs * d.Q * err).sum(1) + (cs[:N] * d.R * np.sum(u ** 2, axis=2)).sum(1)
+        gq = cs[None, :, None] * np.asarray(ev['cost_grad_q'])[:, :, :nq]
+        gu = cs[None, :N, None] * 2.0 * d.R * u
+    else:
+        f, gq, gu = np.zeros(len(x)), np.zeros((len(x), N + 1, nq)), np.zeros_like(u)
+    pos = lambda a: np.maximum(a, 0.0)
+    viol = np.abs(x[:, 0] - x0).sum(1)
+    xn = np.empty_like(x[:, 1:])
+    xn[:, :, :nq] = x[:, :-1, :nq] + dt * x[:, :-1, nq:] + 0.5 * dt * dt * u
+    xn[:, :, nq:] = x[:, :-1, nq:] + dt * u
+    viol += np.abs(x[:, 1:] - xn).sum(axis=(1, 2))
+    lo = np.tile(pr.lbx, (N + 1, 1)); hi = np.tile(pr.ubx, (N + 1, 1))
+    lo[N], hi[N] = pr.lbx_e, pr.ubx_e
+    viol += (pos(lo[1:] - x[:, 1:]) + pos(x[:, 1:] - hi[1:])).sum(axis=(1, 2))
+    tau = np.asarray(ev['tau'])[:, :N, :nq]
+    viol += pos(np.abs(tau) - pr.tau_max).sum(axis=(1, 2))
+    if d.n_rows:
+        rv = np.asarray(ev['row_val'])[:, 1:, :d.n_rows]
+        lb = np.where(np.abs(pr.row_lb) < 1e5, pr.row_lb, -np.inf)
+        ub = np.where(np.abs(pr.row_ub) < 1e5, pr.row_ub, np.inf)
+        viol += (pos(lb - rv) + pos(rv - ub)).sum(axis=(1, 2))
+    if d.nn_mode != 0:
+        g = np.asarray(ev['nn_val'])
+        on = ctrl.p[:, :, 4] > 0
+        on[:, 0] = False
+        if d.nn_mode == 1:
+            on[:, :N] = False
+        viol += (pos(-g) * on).sum(1)
+    return f, gq, gu, viol
+
+
+def generate_guess(params, cont_name, n, make_controller=None, sqp_tol=1e-6, verbose=False, armijo=1e-4, alpha_reduction=0.7,
+                   alpha_min=0.05, history=None):
     """guess_acados.py:98-158: Halton q0 in the joint box, collision filter, constant guess, SQP to convergence, checkGuess.
 
-    The reference runs acados' SQP with merit backtracking (parser.py:117,139); here the SQP loop is the engine's RTI step
-    applied repeatedly with full steps until the iterate stops moving (documented deviation: no line search).
-    Returns dict(xg [m,N+1,nx], ug [m,N,nu]) of the accepted instances, in sampling order.
-    """
+    SQP with merit backtracking (the reference runs acados with nlp_solver_type SQP, globalization MERIT_BACKTRACKING,
+    parser.py:115-117,139): every iteration solves the engine's stage QP at the current iterate (one RTI solve from it),
+    then backtracks the step length per instance on the l1 merit  f + mu |c|_1  until the Armijo condition
+    merit(alpha) <= merit(0) + armijo * alpha * (grad f . d - mu |c(0)|_1)  holds (factor ``alpha_reduction``, floor
+    ``alpha_min`` at which the step is taken regardless -- acados' defaults 0.7 / 0.05 [EXT-UNVERIFIED]; the reference parses
+    alpha_reduction / alpha_min from config.yaml but never hands them to acados, parser.py:119-120).  The penalty mu grows
+    so that the QP step is a descent direction of the merit.  All instances advance together; one batched linearisation per
+    trial step length.  Returns (dict(xg [m,N+1,nx], ug [m,N,nu]) of the accepted instances in sampling order, good mask);
+    ``history`` (a list) receives the per-iteration merit values [B] for inspection."""
     make_controller = make_controller or (lambda name, batch: get_controller(name, params, batch))
     ctrl = make_controller(cont_name, n)
     pr = ctrl.problem
@@ -106,21 +156,44 @@ def generate_guess(params, cont_name, n, make_controller=None, sqp_tol=1e-6, ver
     ctrl.setGuess(np.repeat(x0[:, None, :], ctrl.N + 1, axis=1), np.zeros((B, ctrl.N, ctrl.nu)))
     done = np.zeros(B, bool)
     status = np.zeros(B, np.int32)
+    mu = np.full(B, 10.0)
     for it in range(int(params.nlp_max_iter)):
         st = ctrl.solve(x0)
-        step = np.maximum(np.abs(ctrl.x_temp - ctrl.x_guess).reshape(B, -1).max(1),
-                          np.abs(ctrl.u_temp - ctrl.u_guess).reshape(B, -1).max(1))
-        upd = ~done
-        ctrl.x_guess = np.where(upd[:, None, None], ctrl.x_temp, ctrl.x_guess)
-        ctrl.u_guess = np.where(upd[:, None, None], ctrl.u_temp, ctrl.u_guess)
-        status = np.where(upd, st, status)
-        done |= (step < sqp_tol) | (st != 0)
+        dx, du = ctrl.x_temp - ctrl.x_guess, ctrl.u_temp - ctrl.u_guess
+        step = np.maximum(np.abs(dx).reshape(B, -1).max(1), np.abs(du).reshape(B, -1).max(1))
+        f0, gq, gu, c0 = merit_terms(ctrl, x0, ctrl.x_guess, ctrl.u_guess)
+        gd = (gq * dx[:, :, :nq]).sum(axis=(1, 2)) + (gu * du).sum(axis=(1, 2))
+        # penalty large enough for  D = grad f . d - mu |c|_1 < 0  wherever the iterate is infeasible
+        need = np.where(c0 > 1e-12, 2.0 * np.maximum(gd, 0.0) / np.maximum(c0, 1e-12), 0.0)
+        mu = np.minimum(np.maximum(mu, need), 1e8)
+        m0 = f0 + mu * c0
+        D = gd - mu * c0
+        alpha = np.ones(B)
+        settled = done | (st != 0)
+        while True:
+            xt = ctrl.x_guess + alpha[:, None, None] * dx
+            ut = ctrl.u_guess + alpha[:, None, None] * du
+            ft, _, _, ct = merit_terms(ctrl, x0, xt, ut)
+            ok = (ft + mu * ct <= m0 + armijo * alpha * np.minimum(D, 0.0) + 1e-12 * (1.0 + np.abs(m0)))
+            settled = settled | ok | (alpha <= alpha_min)
+            if settled.all():
+                break
+            alpha = np.where(settled, alpha, np.maximum(alpha * alpha_reduction, alpha_min))
+        upd = ~done & (st == 0)
+        ctrl.x_guess = np.where(upd[:, None, None], xt, ctrl.x_guess)
+        ctrl.u_guess = np.where(upd[:, None, None], ut, ctrl.u_guess)
+        status = np.where(~done, st, status)
+        if history is not None:
+            history.append({'merit': np.where(upd, ft + mu * ct, m0), 'merit_before': m0.copy(), 'alpha': np.where(upd, alpha, 0.0),
+                            'mu': mu.copy(), 'violation': np.where(upd, ct, c0), 'updated': upd.copy()})
+        done |= (alpha * step < sqp_tol) | (st != 0)
         if verbose:
-            print(f'SQP iteration {it}: {done.sum()}/{B} done, max step {step[upd].max() if upd.any() else 0:.2e}')
+            print(f'SQP iteration {it}: {done.sum()}/{B} done, max step {step[upd].max() if upd.any() else 0:.2e}, '
+                  f'min alpha {alpha[upd].min() if upd.any() else 1:.2f}')
         if done.all():
             break
     ctrl.x_temp, ctrl.u_temp = ctrl.x_guess.copy(), ctrl.u_guess.copy()
-    good = (status == 0) & done & ctrl.checkGuess()
+    good = ((status == 0) | (status == 2)) & ctrl.checkGuess()              # guess_acados.py:115 accepts status 0 or 2
     return {'xg': ctrl.x_guess[good], 'ug': ctrl.u_guess[good]}, good
 
 

@@ -72,3 +72,42 @@ def test_masked_step_leaves_inactive_rows_untouched():
     u, ab = cl._masked_step(c, x0, np.array([True, False, True]))
     assert np.array_equal(c.x_guess[1], before[0][1]) and c.current_step.tolist() == [1, 0, 1]
     assert not ab[1]
+
+
+def _merit_sqp_checks(mk, par, cont, n):
+    hist = []
+    guess, good = cl.generate_guess(par, cont, n, make_controller=mk, sqp_tol=1e-6, history=hist)
+    assert good.sum() >= 1 and len(hist) >= 2
+    # the l1 merit never increases along the accepted steps (Armijo, parser.py:139 MERIT_BACKTRACKING): compared at equal mu
+    for h in hist:
+        up = h['updated'] & (h['alpha'] > 0.05)
+        assert np.all(h['merit'][up] <= h['merit_before'][up] + 1e-9 * (1 + np.abs(h['merit_before'][up])))
+    assert max(h['alpha'].max() for h in hist) == 1.0                 # full steps are taken when they are good ...
+    viol_end = hist[-1]['violation']
+    assert np.all(viol_end[good] < 1e-5)                              # ... and the accepted guesses are feasible
+    return guess, good, hist
+
+
+def test_generate_guess_merit_backtracking_on_oracle_double():
+    """guess_acados.py:98-158 with parser.py:139 MERIT_BACKTRACKING: merit decrease, feasibility of accepted guesses, and a
+    start far from feasibility (default LM 0.5, aggressive reference) where the step length actually has to be cut."""
+    par, prob, net = make_problem('naive', N=8)
+    par.nlp_max_iter = 150
+    par.levenberg_marquardt = 1e-3
+    mk, _ = _factories(par, 8)
+    guess, good, hist = _merit_sqp_checks(mk, par, 'naive', 6)
+    # guesses pass the reference's acceptance test (checkGuess: state, torque, dynamics) by construction of `good`
+    assert guess['xg'].shape[0] == good.sum()
+    # NLS cost + terminal zero velocity (the OCP guess_acados.py builds for naive / zerovel warm starts)
+    par2, prob2, net2 = make_problem('zerovel', 'nls', N=8)
+    par2.nlp_max_iter, par2.levenberg_marquardt = 150, 1e-3
+
+    def mk2(name, batch):
+        cls = C.CONTROLLERS[name]
+        ctrl = cls.__new__(cls)
+        prob = C.OcpProblem(par2, cls.cont_name, 'nls', N=8)
+        net = C.SafeSetNet.from_params(par2, prob.x_min, prob.x_max)
+        prob.set_normalisation(net.mean, net.std)
+        C.AbstractController.__init__(ctrl, par2, batch, 'nls', 8, solver=OracleSolver(prob, net), net=net)
+        return ctrl
+    _merit_sqp_checks(mk2, par2, 'zerovel', 4)

@@ -442,3 +442,25 @@ def test_device_resident_policy_layer_equals_host_automaton(name):
     assert np.nanmax(np.abs(host['x'] - dev['x'])) < 1e-9 and np.nanmax(np.abs(host['u'] - dev['u'])) < 1e-7
     if host['x_viable'].size:
         assert np.abs(host['x_viable'] - dev['x_viable']).max() < 1e-9
+
+
+def test_generate_guess_merit_backtracking_on_engine():
+    """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
+    engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
+    safe-set OCP ('htwa', what every safe-set controller's warm start is generated with) ends feasible."""
+    from safe_mpc_amd import closed_loop as cl
+    from safe_mpc_amd import controller as C
+    from safe_mpc_amd.parser import Parameters
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N, par.nlp_max_iter = 6, 6, [12, 256, 1], 20, 200
+    hist = []
+    guess, good = cl.generate_guess(par, 'htwa', 48, history=hist)
+    assert good.sum() >= 24 and guess['xg'].shape == (good.sum(), 21, 12)
+    for h in hist:
+        up = h['updated'] & (h['alpha'] > 0.05)
+        assert np.all(h['merit'][up] <= h['merit_before'][up] + 1e-9 * (1 + np.abs(h['merit_before'][up])))
+    assert np.all(hist[-1]['violation'][good] < 1e-5)
+    # the accepted guesses pass the reference's acceptance test when re-checked from scratch
+    ctrl = C.get_controller('htwa', par, int(good.sum()))
+    ctrl.x_temp, ctrl.u_temp = guess['xg'].copy(), guess['ug'].copy()
+    assert np.all(ctrl.checkGuess())
