@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 1
+#define SMPC_ABI_VERSION 2
 
 #define SMPC_MAX_NQ 7
 #define SMPC_MAX_NX 14
@@ -131,7 +131,10 @@ typedef struct {
     double nn_eps;             /* config.yaml:48 */
     double nn_soft_e;          /* L1 slack weight on the terminal NN row (zl_e, controller.py:348-354); < 0 = hard */
     double nn_soft_run;        /* same for running nodes; < 0 = hard */
-    double qp_tol;             /* IPM exit tolerance on residuals and complementarity */
+    double qp_tol;             /* IPM exit tolerance on the complementarity (mean lambda t) */
+    double qp_tol_res;         /* ... and on the linear residuals (stationarity, dynamics, slack definitions); 0 = qp_tol.
+                                * HPIPM's BALANCE mode (config.yaml:15) asks 1e-6 of the stationarity residual and 1e-8 of the
+                                * others [EXT-UNVERIFIED]; the engine's default is 1e-8 for both */
     double qp_mu0;             /* IPM initial barrier */
     double gravity[3];
     double nn_mean[SMPC_MAX_NQ];

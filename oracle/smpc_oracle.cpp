@@ -475,7 +475,7 @@ struct Stage {
 
 struct QpOpts {
     int max_iter;
-    double tol, mu0;
+    double tol, tol_res, mu0;   /* complementarity / linear-residual exit tolerances */
 };
 
 /* returns 0 converged, 2 max-iter, 3 min-step, 4 breakdown (non-PD pivot / NaN) */
@@ -791,7 +791,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
 
     double mu = mu_now();
     for (it = 0; it < o.max_iter; it++) {
-        if (mu <= o.tol && rho * R0 <= o.tol) { status = 0; break; }
+        if (mu <= o.tol && rho * R0 <= o.tol_res) { status = 0; break; }
         if (!factorize()) { status = 4; break; }
         /* predictor */
         solve(0.0, false);
@@ -849,7 +849,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
                          it, a_aff, sigma, alpha, mu, rho * R0, blk_k, blk_r, S[blk_k].tl[blk_r], S[blk_k].ll[blk_r], S[blk_k].tu[blk_r], S[blk_k].lu[blk_r]);
         if (!(mu == mu)) { status = 4; break; }
     }
-    if (it == o.max_iter && status == 2 && mu <= o.tol && rho * R0 <= o.tol) status = 0;
+    if (it == o.max_iter && status == 2 && mu <= o.tol && rho * R0 <= o.tol_res) status = 0;
     *iters = it;
     if (res_out) { res_out[0] = mu; res_out[1] = rho * R0; }
     return status;
@@ -1103,7 +1103,7 @@ int orc_solve_batch(void* h, int B, const double* x0, const double* xg, const do
     Oracle* o = (Oracle*)h;
     const smpc_problem_desc& D = o->D;
     int N = o->N, nq = D.nq, nx = 2 * nq, nu = nq;
-    QpOpts qo{D.qp_max_iter, D.qp_tol, D.qp_mu0};
+    QpOpts qo{D.qp_max_iter, D.qp_tol, D.qp_tol_res > 0.0 ? D.qp_tol_res : D.qp_tol, D.qp_mu0};
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; b++) {
         const double* xb = xg + (size_t)b * (N + 1) * nx;

@@ -658,6 +658,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     bool pending = false;  // a step (alpha, directions, z+) computed by F2 and not yet applied to state / z
     int it = 0, st_code = 2;
     const double tol = D->qp_tol;
+    const double tol_r = D->qp_tol_res > 0.0 ? D->qp_tol_res : D->qp_tol;
     const int max_iter = D->qp_max_iter;
     bool broke = false;
     double *Pc = sIMG + O_PA, *Pn = sIMG + O_PB2;    // P_{k+1} (in use) / P_k (being built)
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     lds_fence();
 
     for (it = 0; it < max_iter; it++) {
-        if (mu <= tol && rho_lin * R0 <= tol) { st_code = 0; break; }
+        if (mu <= tol && rho_lin * R0 <= tol_r) { st_code = 0; break; }
 
         // ---------------- sweep B1: apply the pending step, factorise H + C^T D C, predictor costate ----------------------
         // (alpha = 0 and zero directions before the first step: the update is applied unconditionally)
@@ -1154,7 +1155,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         mu = (mu * (double)m_comp + alpha * S1c + alpha * alpha * S2c) * inv_m;
         if (!(mu == mu)) { st_code = 4; pending = false; break; }
     }
-    if (it == max_iter && st_code == 2 && mu <= tol && rho_lin * R0 <= tol) st_code = 0;
+    if (it == max_iter && st_code == 2 && mu <= tol && rho_lin * R0 <= tol_r) st_code = 0;
 
     // ---- full SQP step (FIXED_STEP, parser.py:139), applying the last IPM step if it is still pending -------------------
     bool bad = false;

@@ -14,7 +14,7 @@ import numpy as np
 
 from .urdf import SerialChain
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_NQ, MAX_NX, MAX_POINTS, MAX_ROWS, MAX_LAYERS, MAX_N, NP = 7, 14, 12, 12, 6, 63, 5
 INF = 1.0e5
 
@@ -49,7 +49,7 @@ class ProblemDesc(C.Structure):
                 ('dt', C.c_double), ('Q', C.c_double), ('R', C.c_double), ('cost_scale_stage', C.c_double),
                 ('cost_scale_term', C.c_double), ('lm_stage', C.c_double), ('lm_term', C.c_double),
                 ('nn_eps', C.c_double), ('nn_soft_e', C.c_double), ('nn_soft_run', C.c_double),
-                ('qp_tol', C.c_double), ('qp_mu0', C.c_double), ('gravity', C.c_double * 3),
+                ('qp_tol', C.c_double), ('qp_tol_res', C.c_double), ('qp_mu0', C.c_double), ('gravity', C.c_double * 3),
                 ('nn_mean', C.c_double * MAX_NQ), ('nn_std', C.c_double * MAX_NQ),
                 ('x_lo', C.c_double * MAX_NX), ('x_hi', C.c_double * MAX_NX),
                 ('x_lo_e', C.c_double * MAX_NX), ('x_hi_e', C.c_double * MAX_NX),
@@ -258,7 +258,8 @@ class OcpProblem:
         d.rows_at_node0 = int(not float(getattr(params, 'noise', 0.0) or 0.0) > 0.0) if rows_at_node0 is None \
             else int(bool(rows_at_node0))
         d.qp_max_iter = params.qp_max_iter
-        d.qp_tol, d.qp_mu0 = 1e-8, 1.0
+        d.qp_tol, d.qp_mu0 = float(getattr(params, 'qp_tol', 1e-8)), 1.0
+        d.qp_tol_res = float(getattr(params, 'qp_tol_res', 0.0))     # 0: same as qp_tol
         self.desc = d
 
     # -- helpers ----------------------------------------------------------------------------------------------------
