@@ -66,7 +66,8 @@ template <int NQ> struct QpLayout {
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
-    int oC, oIMG, oW, oSL, oR0, oR1, oR2, oR3;                  // 16-byte aligned blocks
+    int nC;                                                     // doubles of the compact general rows
+    int oC, oIMG, oW, oSL, oAUX, oR0, oR1, oR2, oR3;            // 16-byte aligned blocks
     int oZ, oZN, oGH0, oA1, oA2, oPB, oPART;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
@@ -84,10 +85,14 @@ template <int NQ> struct QpLayout {
         iSC = i; i += 4;                   // [Huu diagonal, LM on the v diagonal, soft weight, b != 0]
         nIMG = i;                          // (even)
         int o = 0;
-        oC = o; o += NRC * NZP;            // general rows, row-major (staged through LDS by the forward sweeps)
+        // general rows without their structural zeros: [torque rows NQ x NZP | collision rows MR x NQP (the q columns) |
+        // safe-set row NX (the x columns)]; the forward sweeps scatter the pieces into a row-major NRC x NZP image in LDS
+        nC = NQ * NZP + MR * NQP + NX;
+        oC = o; o += nC;
         oIMG = o; o += nIMG;
         oW = o; o += NQ * KS;              // factor rows [W_i | w_i | . | row i of L^-1]
         oSL = o; o += 2;                   // [soft weight, b != 0]
+        oAUX = o; o += 2 * NX;             // per state lane, as pairs: [b_i, soft weight]  (one load in the forward sweeps)
         oR0 = o; o += NRT * 2;             // per row, as arrays of pairs: [lo, hi]
         oR1 = o; o += NRT * 2;             //   [t_l, t_u]        (the soft row has no upper side: its slack lives in t_u)
         oR2 = o; o += NRT * 2;             //   [lambda_l, lambda_u]
@@ -377,7 +382,15 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
     const double bflag = bmax > 0.0 ? 1.0 : 0.0;
 
     // ---- static blocks out ---------------------------------------------------------------------------------------------
-    for (int el = hl; el < NRC * NZP; el += 32) w[Ly.oC + el] = sC[el];
+    for (int el = hl; el < Ly.nC; el += 32) {
+        int src;   // position in the row-major image, -1 = padding
+        if (el < NQ * NZP) src = el;
+        else if (el < NQ * NZP + MR * NQP) {
+            const int t = el - NQ * NZP, r = t / NQP, ix = t - r * NQP;
+            src = ix < NQ ? (NQ + r) * NZP + NU + ix : -1;
+        } else src = (NQ + MR) * NZP + NU + (el - NQ * NZP - MR * NQP);
+        w[Ly.oC + el] = src >= 0 ? sC[src] : 0.0;
+    }
     if (hl < NRT) { w[Ly.oR0 + 2 * hl] = sLO[hl]; w[Ly.oR0 + 2 * hl + 1] = sHI[hl]; }
     double* img = w + Ly.oIMG;
     for (int el = hl; el < NZ * NQP; el += 32) {
@@ -451,6 +464,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
         sE[r] = -(ll - lu);
     }
     if (hl < 2) w[Ly.oSL + hl] = hl == 0 ? wsoft : bflag;
+    if (hl < NX) { w[Ly.oAUX + 2 * hl] = sB[hl]; w[Ly.oAUX + 2 * hl + 1] = wsoft; }
     if (hl < NZ) { w[Ly.oZ + hl] = sZ0[hl]; w[Ly.oZN + hl] = sZ0[hl]; }
     if (hl < NX) w[Ly.oPB + hl] = 0.0;
     lds_fence();
@@ -506,7 +520,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
     constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
     constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
-    constexpr int CST_MAX = NRC_MAX * NZP, CST_PF = (CST_MAX / 2 + 31) / 32;   // general rows staged by the forward sweeps
+    constexpr int CST_MAX = NRC_MAX * NZP;                                       // row-major image of the general rows in LDS
+    constexpr int NC_MAX = NQ * NZP + MR_MAX * NQP + NX, CST_PF = (NC_MAX / 2 + 31) / 32;   // ... fetched without its zeros
+    static_assert(NQ * NZP / 2 >= 32, "the first piece of every lane lies in the torque rows");
     constexpr int W_N2 = NQ * KS / 2, WST_PF = (W_N2 + 31) / 32;                 // ... and the factor block
     // (staged in LDS by the other sweeps, in the buffers that only the factorisation sweep uses)
 #ifdef QP_PROFILE
@@ -525,7 +541,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const ws = ws_all + (size_t)b * Ly.per_instance(N);
     const double dt = D->dt, cB = 0.5 * dt * dt;
     const int img_n2 = Ly.nIMG >> 1;   // 16-byte pieces of the image
-    const int c_n2 = (Ly.NRC * NZP) >> 1;   // ... and of the general rows
+    const int c_n2 = Ly.nC >> 1;            // ... and of the compact general rows
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
     // [image | D | E | -- buffers of the factorisation sweep only: TD GD Lambda G Wt Hxx P P -- | vectors]
@@ -912,6 +928,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             int o_wc = O_TD + CST_MAX, o_wn = O_TD + CST_MAX + NQ * KS;    // factor block of this stage / of the next one
             dbl2 Cs[CST_PF], Ws[WST_PF], r0, r1, r2, r3;
             double bi, wsoft;
+            // where piece j of this lane goes in the row-major LDS image (in doubles).  Piece 0 is always in the torque rows,
+            // which the two layouts share; the collision / safe-set pieces move behind their rows' zero u columns.
+            int cdst[CST_PF];
+#pragma unroll
+            for (int j = 0; j < CST_PF; j++) {
+                const int e = 2 * min(hl + 32 * j, c_n2 - 1);
+                int dmap = e;
+                if (e >= NQ * NZP + MR * NQP) dmap = (NQ + MR) * NZP + NU + (e - NQ * NZP - MR * NQP);
+                else if (e >= NQ * NZP) {
+                    const int t = e - NQ * NZP, r = t / NQP;
+                    dmap = (NQ + r) * NZP + NU + (t - r * NQP);
+                }
+                cdst[j] = dmap;
+            }
+            // structural zeros of the image (the factorisation sweep used this LDS for other things): u and v columns of the
+            // collision rows, u columns of the safe-set row -- written once per sweep, the stages only refresh the rest
+            for (int el = hl; el < NRC * NZP; el += 32) {
+                const int r = el / NZP, c = el - r * NZP;
+                const bool keep = r < NQ || (c >= NU && (c < NU + NQ || (r == NQ + MR && c < NZ)));
+                if (!keep) sCst[el] = 0.0;
+            }
             auto load_w = [&](int k) {
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(k) + Ly.oW);
 #pragma unroll
@@ -934,8 +971,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr];
                 r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
                 if (CORR) r3 = reinterpret_cast<const dbl2*>(w + Ly.oR3)[hr];
-                wsoft = w[Ly.oSL];
-                bi = w[Ly.oIMG + Ly.iB + hl_x];
+                const dbl2 aux = reinterpret_cast<const dbl2*>(w + Ly.oAUX)[hl_x];
+                bi = aux.x;
+                wsoft = aux.y;
             };
             if (hl < NX) sIMG[o_xb + hl] = dx0_reg;
             load_w(0);
@@ -959,9 +997,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 double *const xb = sIMG + o_xb, *const xn = sIMG + o_xn, *const wc_ = sIMG + o_wc, *const wn_ = sIMG + o_wn;
                 // general rows -> LDS (rows for the constraint lanes, columns for a1 / a2)
                 {
-                    dbl2* d2 = reinterpret_cast<dbl2*>(sCst);
 #pragma unroll
-                    for (int j = 0; j < CST_PF; j++) d2[min(hl + 32 * j, c_n2 - 1)] = Cs[j];
+                    for (int j = 0; j < CST_PF; j++) {
+                        if constexpr (NQ % 2 == 0) *reinterpret_cast<dbl2*>(sCst + cdst[j]) = Cs[j];   // (NU even: 16-byte aligned)
+                        else { sCst[cdst[j]] = Cs[j].x; sCst[cdst[j] + 1] = Cs[j].y; }
+                    }
                 }
                 load_c(kn);
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
