@@ -7,6 +7,23 @@ from __future__ import annotations
 import numpy as np
 
 
+class InPlaceState:
+    """Mixin: with ``_inplace`` set, assigning a tensor to an attribute that already holds a tensor of the same shape and dtype
+    copies INTO the existing storage instead of rebinding the name.  The policy code keeps its plain ``self.fails = ...``
+    statements, and every piece of per-instance state stays at a fixed address in HBM -- which is what lets a whole
+    closed-loop step be captured once as a hipGraph and replayed (closed_loop.py)."""
+    _inplace = False
+
+    def __setattr__(self, name, value):
+        if self.__dict__.get('_inplace') and not name.startswith('_'):
+            cur = self.__dict__.get(name)
+            if (cur is not None and hasattr(cur, 'copy_') and hasattr(value, 'dtype') and cur is not value
+                    and tuple(cur.shape) == tuple(getattr(value, 'shape', ())) and cur.dtype == value.dtype):
+                cur.copy_(value)
+                return
+        object.__setattr__(self, name, value)
+
+
 class NumpyOps:
     name = 'numpy'
     on_device = False
@@ -69,6 +86,19 @@ class NumpyOps:
 
     def host(self, a):
         return np.asarray(a)
+
+    # step-indexed logs: `j` is a python int here, a one-element device tensor on the torch backend
+    def step_index(self, j0=0):
+        return [j0]
+
+    def put_row(self, log, j, value, offset=0):
+        log[j[0] + offset] = value
+
+    def step_vec(self, j, n, offset=0):
+        return np.full(n, j[0] + offset, np.int64)
+
+    def step_advance(self, j):
+        j[0] += 1
 
 
 class TorchOps:
@@ -136,3 +166,15 @@ class TorchOps:
 
     def host(self, a):
         return a.detach().cpu().numpy()
+
+    def step_index(self, j0=0):
+        return self.t.full((1,), j0, dtype=self.i64, device=self.device)
+
+    def put_row(self, log, j, value, offset=0):
+        log.index_copy_(0, j + offset if offset else j, value[None])
+
+    def step_vec(self, j, n, offset=0):
+        return (j + offset).expand(n)
+
+    def step_advance(self, j):
+        j.add_(1)

@@ -15,6 +15,7 @@ import pickle
 
 import numpy as np
 
+from ._xp import InPlaceState
 from .controller import SafeBackupController, get_controller
 from .problem import JOINT_DTYPE
 from .urdf import Inertial, Origin, RobotDescription, SerialChain
@@ -213,154 +214,209 @@ def _masked_step(ctrl, x, active):
     return u, abort & active
 
 
-def _group_loop(params, cont_name, x_guess, u_guess, noise, control_noise, ctrl, backup, n_steps, first, callback, out):
-    """Generator running the closed loop of ONE group of instances (global indices first .. first + B); yields once per step
-    at the point where the host needs the step's single scalar from the device, so that the caller can enqueue the other
-    groups' work in the meantime (run_mpc).  Fills ``out`` with the group's result pieces when exhausted."""
-    B = x_guess.shape[0]
-    xp = ctrl.xp
-    pr, nq, nx, nu = ctrl.problem, ctrl.nq, ctrl.nx, ctrl.nu
-    kp, kd = 1.0, 1e2                                                               # mpc.py:97
-    Nb = backup.N
-    solver = ctrl.ocp_solver
+class _Group(InPlaceState):
+    """The closed loop of ONE group of instances (global indices first .. first + B): the driver's safe-abort automaton around
+    the controller's ``step``.  A step has two enqueue-only halves, :meth:`part_a` (PD abort tracking, controller step) and
+    :meth:`part_b` (plant, outcome tests, logs), with the step's single host decision between them (``did any instance
+    raise abort?``).  On the device every state array keeps its address (InPlaceState), so after a few eager steps each half
+    is captured once as a hipGraph and replayed: one graph launch instead of ~50 kernel launches per half."""
 
-    seeds = np.arange(first, first + B)
-    joints_noisy = perturbed_joint_tables(params, nq, noise, seeds) if noise > 0 else None          # mpc.py:106-107
-    # model.reset_seed(i) is called at EVERY step (mpc.py:126): each instance sees the same torque-noise draw each step
-    tau_noise = None
-    if control_noise > 0:
-        tau_noise = np.stack([np.random.default_rng(int(i)).normal(np.zeros(nu), pr.tau_max * control_noise / 100, nu)
-                              for i in seeds])
-    if xp.on_device:
-        if joints_noisy is not None:          # [B, nq] smpc_joint records as a float64 tensor (33 doubles each)
-            joints_noisy = xp.asarray(np.ascontiguousarray(joints_noisy).view(np.float64).reshape(B, nq, -1), xp.f64)
-        if tau_noise is not None:
-            tau_noise = xp.asarray(tau_noise, xp.f64)
-    x_min, x_max = xp.asarray(pr.x_min, xp.f64), xp.asarray(pr.x_max, xp.f64)
+    def __init__(self, params, x_guess, u_guess, noise, control_noise, ctrl, backup, n_steps, first, callback, use_graphs):
+        self._params, self._ctrl, self._backup, self._n_steps, self._first, self._callback = params, ctrl, backup, n_steps, first, callback
+        B = x_guess.shape[0]
+        xp = ctrl.xp
+        self._xp, self._B = xp, B
+        pr, nq, nx, nu = ctrl.problem, ctrl.nq, ctrl.nx, ctrl.nu
+        self._Nb = backup.N
+        seeds = np.arange(first, first + B)
+        joints_noisy = perturbed_joint_tables(params, nq, noise, seeds) if noise > 0 else None          # mpc.py:106-107
+        # model.reset_seed(i) is called at EVERY step (mpc.py:126): each instance sees the same torque-noise draw each step
+        tau_noise = None
+        if control_noise > 0:
+            tau_noise = np.stack([np.random.default_rng(int(i)).normal(np.zeros(nu), pr.tau_max * control_noise / 100, nu)
+                                  for i in seeds])
+        if xp.on_device:
+            if joints_noisy is not None:          # [B, nq] smpc_joint records as a float64 tensor (33 doubles each)
+                joints_noisy = xp.asarray(np.ascontiguousarray(joints_noisy).view(np.float64).reshape(B, nq, -1), xp.f64)
+            if tau_noise is not None:
+                tau_noise = xp.asarray(tau_noise, xp.f64)
+        self._joints_noisy, self._tau_noise = joints_noisy, tau_noise
+        # step-major logs (one contiguous [B, .] slab per step); transposed to the reference's [B, step, .] at the end
+        nan = float('nan')
+        self.x_log = xp.full((n_steps + 1, B, nx), nan)
+        self.u_log = xp.full((n_steps, B, nu), nan)
+        self.r_log = xp.full((n_steps, B), -1, xp.i64)
+        self.x_cur = xp.asarray(x_guess[:, 0], xp.f64)
+        self.x_log[0] = self.x_cur
+        ctrl.setGuess(x_guess, u_guess)                                                  # mpc.py:119-120
+        ctrl.reset_controller()
+        self.alive = xp.full((B,), True, xp.bool_)
+        self.sa = xp.full((B,), False, xp.bool_)
+        self.ja = xp.zeros((B,), xp.i64)
+        self.x_abort = xp.zeros((B, self._Nb + 1, nx))
+        self.u_abort = xp.zeros((B, self._Nb, nu))
+        self.collided = xp.full((B,), False, xp.bool_)
+        self.viable = xp.full((B,), False, xp.bool_)
+        self.u = xp.zeros((B, nu))
+        self.new_abort = xp.full((B,), False, xp.bool_)
+        # last valid row of the state / input logs of every instance (mpc.py:114 pre-fills with NaN, :240-264 and :186-190 break)
+        self.last_x, self.last_u = xp.full((B,), n_steps, xp.i64), xp.full((B,), n_steps - 1, xp.i64)
+        self._jt = xp.step_index(0)           # the step counter (a device tensor on the torch backend: graphs replay it)
+        self._zeros_u = xp.zeros((B, nu))
+        self._abort_events = []
+        self._ever_aborted = False
+        self._use_graphs = bool(use_graphs and xp.on_device)
+        self._graphs = {}                     # (half, ever_aborted) -> captured graph
+        self._inplace = xp.on_device
 
-    # step-major logs (one contiguous [B, .] slab per step); transposed to the reference's [B, step, .] at the end
-    nan = float('nan')
-    x_log = xp.full((n_steps + 1, B, nx), nan)
-    u_log = xp.full((n_steps, B, nu), nan)
-    r_log = xp.full((n_steps, B), -1, xp.i64)
-    x_cur = xp.asarray(x_guess[:, 0], xp.f64)
-    x_log[0] = x_cur
-    ctrl.setGuess(x_guess, u_guess)                                                  # mpc.py:119-120
-    ctrl.reset_controller()
-    alive = xp.full((B,), True, xp.bool_)
-    sa = xp.full((B,), False, xp.bool_)
-    ja = xp.zeros((B,), xp.i64)
-    x_abort = xp.zeros((B, Nb + 1, nx))
-    u_abort = xp.zeros((B, Nb, nu))
-    collided = xp.full((B,), False, xp.bool_)
-    viable = xp.full((B,), False, xp.bool_)
-    x_viable_log = []
-    zeros_u = xp.zeros((B, nu))
-    # last valid row of the state / input logs of every instance (mpc.py:114 pre-fills with NaN, :240-264 and :186-190 break)
-    last_x, last_u = xp.full((B,), n_steps, xp.i64), xp.full((B,), n_steps - 1, xp.i64)
-    ever_aborted = False
-
-    for j in range(n_steps):
-        # --- instances following their safe-abort trajectory (mpc.py:130-146)
-        if ever_aborted:
-            in_abort = sa & alive
-            follow = in_abort & (ja < Nb)
-            idx = xp.clip_max(ja, Nb - 1)
-            xa = xp.take_rows(x_abort, idx)
-            ua = xp.take_rows(u_abort, idx)
+    # ---- first half: everything up to the controller's verdict ---------------------------------------------------------------
+    def part_a(self):
+        xp, ctrl, B, Nb = self._xp, self._ctrl, self._B, self._Nb
+        nq = ctrl.nq
+        kp, kd = 1.0, 1e2                                                               # mpc.py:97
+        x_cur = self.x_cur
+        if self._ever_aborted:
+            # --- instances following their safe-abort trajectory (mpc.py:130-146)
+            in_abort = self.sa & self.alive
+            follow = in_abort & (self.ja < Nb)
+            idx = xp.clip_max(self.ja, Nb - 1)
+            xa = xp.take_rows(self.x_abort, idx)
+            ua = xp.take_rows(self.u_abort, idx)
             u_f = ua - (kp * (x_cur[:, :nq] - xa[:, :nq]) + kd * (x_cur[:, nq:] - xa[:, nq:]))
-            u = xp.where(follow[:, None], u_f, zeros_u)
-            hold = in_abort & (ja >= Nb)
+            u = xp.where(follow[:, None], u_f, self._zeros_u)
+            hold = in_abort & (self.ja >= Nb)
             resume = hold & xp.all_tail(x_cur[:, nq:] < 5e-3)                         # mpc.py:138
             still = hold & ~resume
-            xe = x_abort[:, -1]
+            xe = self.x_abort[:, -1]
             u_h = -(kp * (x_cur[:, :nq] - xe[:, :nq]) + 3e2 * (x_cur[:, nq:] - xe[:, nq:]))
             u = xp.where(still[:, None], u_h, u)
-            sa = sa & ~resume
-            ja = ja + xp.cast(in_abort, xp.i64)
+            self.sa = self.sa & ~resume
+            self.ja = self.ja + xp.cast(in_abort, xp.i64)
         else:
-            u = zeros_u
+            u = self._zeros_u
         # --- instances under MPC (mpc.py:151)
-        stepping = alive & ~sa
+        stepping = self.alive & ~self.sa
         if hasattr(ctrl, 'r'):
-            r_log[j] = xp.where(stepping, ctrl.r, r_log[j])
+            xp.put_row(self.r_log, self._jt, xp.where(stepping, ctrl.r, xp.full((B,), -1, xp.i64)))
         # (until the first abort event every live instance steps: no snapshot / roll-back needed; dead instances are never
         #  read again, so they may step along)
-        if ever_aborted:
+        if self._ever_aborted:
             u_m, ab = _masked_step(ctrl, x_cur, stepping)
         else:
             u_m, ab = ctrl.step(x_cur)
-        u = xp.where(stepping[:, None], u_m, u)
-        new_abort = ab & stepping
-        yield j                                   # everything up to here is enqueued; the caller serves the other groups
-        if ctrl.can_abort and xp.any(new_abort):                                     # mpc.py:161-190 (the step's one host sync)
-            ever_aborted = True
-            # the backup OCP is solved for the aborting instances only (a compact batch), from their viable states
-            rows = np.where(xp.host(new_abort))[0]
-            xv = ctrl.getLastViableState()
-            rows_b = xp.asarray(rows, xp.i64)
-            xv_c = xv[rows_b]
-            n_c = len(rows)
-            xg_c = xp.repeat_nodes(xv_c, Nb + 1)
-            xo_c, uo_c, st_c, _ = backup.ocp_solver.solve(xv_c if xp.on_device else np.ascontiguousarray(xv_c), xg_c,
-                                                          xp.zeros((n_c, Nb, nu)), backup.p[:n_c])
-            x_viable_log.append((rows + first, np.full(n_c, j), xp.host(xv_c)))
-            ok_c = st_c == 0 if xp.on_device else np.asarray(st_c) == 0
-            failed = xp.full((B,), False, xp.bool_)
-            okb = xp.full((B,), False, xp.bool_)
-            failed[rows_b] = ~ok_c
-            okb[rows_b] = ok_c
-            xa_new, ua_new = xp.copy(x_abort), xp.copy(u_abort)
-            xa_new[rows_b] = xo_c if xp.on_device else np.asarray(xo_c)
-            ua_new[rows_b] = uo_c if xp.on_device else np.asarray(uo_c)
-            collided = collided | failed
-            alive = alive & ~failed
-            jj = xp.full((B,), j, xp.i64)
-            last_x, last_u = xp.where(failed, jj, last_x), xp.where(failed, jj, last_u)   # mpc.py:186-190: u[j] is set, x[j+1] never
-            x_abort = xp.where(okb[:, None, None], xa_new, x_abort)
-            u_abort = xp.where(okb[:, None, None], ua_new, u_abort)
-            ja = ja * xp.cast(~okb, xp.i64)
-            sa = sa | okb
-            viable = viable | okb
-        # --- plant (mpc.py:240, env_model.py:192-206).  Logs are written unmasked; rows of an instance after its failure are
+        self.u = xp.where(stepping[:, None], u_m, u)
+        self.new_abort = ab & stepping
+
+    # ---- the step's host decision: abort events (mpc.py:161-190) -----------------------------------------------------------------
+    def handle_aborts(self):
+        xp, ctrl, backup, B, Nb = self._xp, self._ctrl, self._backup, self._B, self._Nb
+        if not (ctrl.can_abort and xp.any(self.new_abort)):                         # (the step's one host synchronisation)
+            return
+        self._ever_aborted = True
+        # the backup OCP is solved for the aborting instances only (a compact batch), from their viable states
+        rows = np.where(xp.host(self.new_abort))[0]
+        j = int(xp.host(self._jt)[0]) if xp.on_device else self._jt[0]
+        xv = ctrl.getLastViableState()
+        rows_b = xp.asarray(rows, xp.i64)
+        xv_c = xv[rows_b]
+        n_c = len(rows)
+        xg_c = xp.repeat_nodes(xv_c, Nb + 1)
+        xo_c, uo_c, st_c, _ = backup.ocp_solver.solve(xv_c if xp.on_device else np.ascontiguousarray(xv_c), xg_c,
+                                                      xp.zeros((n_c, Nb, ctrl.nu)), backup.p[:n_c])
+        self._abort_events.append((rows + self._first, np.full(n_c, j), xp.host(xv_c)))
+        ok_c = st_c == 0 if xp.on_device else np.asarray(st_c) == 0
+        failed = xp.full((B,), False, xp.bool_)
+        okb = xp.full((B,), False, xp.bool_)
+        failed[rows_b] = ~ok_c
+        okb[rows_b] = ok_c
+        xa_new, ua_new = xp.copy(self.x_abort), xp.copy(self.u_abort)
+        xa_new[rows_b] = xo_c if xp.on_device else np.asarray(xo_c)
+        ua_new[rows_b] = uo_c if xp.on_device else np.asarray(uo_c)
+        self.collided = self.collided | failed
+        self.alive = self.alive & ~failed
+        jj = xp.step_vec(self._jt, B)
+        self.last_x, self.last_u = xp.where(failed, jj, self.last_x), xp.where(failed, jj, self.last_u)   # mpc.py:186-190
+        self.x_abort = xp.where(okb[:, None, None], xa_new, self.x_abort)
+        self.u_abort = xp.where(okb[:, None, None], ua_new, self.u_abort)
+        self.ja = self.ja * xp.cast(~okb, xp.i64)
+        self.sa = self.sa | okb
+        self.viable = self.viable | okb
+
+    # ---- second half: plant, outcome tests, logs ----------------------------------------------------------------------------------
+    def part_b(self):
+        xp, ctrl, B = self._xp, self._ctrl, self._B
+        solver = ctrl.ocp_solver
+        # plant (mpc.py:240, env_model.py:192-206).  Logs are written unmasked; rows of an instance after its failure are
         # blanked at the end from the step it died at (mpc.py:114 pre-fills them with NaN)
-        u_log[j] = u
-        x_next, _ = solver.plant_step(x_cur, u, joints_noisy, tau_noise)
-        # --- outcome tests on the new state (mpc.py:246-264): one node per instance, so the engine's box + collision test
+        xp.put_row(self.u_log, self._jt, self.u)
+        x_next, _ = solver.plant_step(self.x_cur, self.u, self._joints_noisy, self._tau_noise)
+        # outcome tests on the new state (mpc.py:246-264): one node per instance, so the engine's box + collision test
         # (model bounds widened by tol_x, rows against the check bounds) is exactly checkStateConstraints
         okn = solver.check_trajectory(x_next[:, None, :] if not xp.on_device else x_next[:, None, :].contiguous())
         okn = (okn != 0) if xp.on_device else np.asarray(okn)
-        x_log[j + 1] = x_next
-        bad = alive & ~okn
-        jj = xp.full((B,), j, xp.i64)
-        last_x, last_u = xp.where(bad, jj + 1, last_x), xp.where(bad, jj, last_u)   # the failing state j+1 stays in the log
-        collided = collided | bad
-        alive = alive & ~bad
-        x_cur = xp.where(alive[:, None], x_next, x_cur)
-        if callback and j % 50 == 0:
-            print(f'step {j} (instances {first}..{first + B - 1}): alive {int(xp.host(alive).sum())}/{B}, '
-                  f'in abort {int(xp.host(sa & alive).sum())}, failures {int(xp.host(collided).sum())}')
-        if not xp.on_device and not alive.any():
-            break
-    if xp.on_device:
-        solver.sync()
-    # convergence at the last step (mpc.py:273): the reference tests x_sim[-1], NaN for instances that broke
-    x_last = x_log[n_steps]
-    ev = solver.eval_nodes(xp.repeat_nodes(xp.nan_to_num(x_last), ctrl.N + 1), xp.zeros((B, ctrl.N, nu)), ctrl.p)
-    ee = xp.host(ev['ee'])[:, 0, :]
-    x_sim = np.ascontiguousarray(np.transpose(xp.host(x_log), (1, 0, 2)))
-    u_sim = np.ascontiguousarray(np.transpose(xp.host(u_log), (1, 0, 2)))
-    steps = np.arange(n_steps + 1)[None, :]
-    x_sim[steps > xp.host(last_x)[:, None]] = np.nan
-    u_sim[steps[:, :n_steps] > xp.host(last_u)[:, None]] = np.nan
-    conv = xp.host(alive) & ~np.isnan(x_sim[:, -1]).any(1) & (np.linalg.norm(ee - pr.ee_ref, axis=1) < params.tol_conv)
-    out.update(x=x_sim, u=u_sim,
-               r_receding=np.transpose(xp.host(r_log), (1, 0))[:, :, None], conv=conv, collided=xp.host(collided),
-               viable=xp.host(viable), abort_events=x_viable_log)
+        xp.put_row(self.x_log, self._jt, x_next, offset=1)
+        bad = self.alive & ~okn
+        jj = xp.step_vec(self._jt, B)
+        self.last_x, self.last_u = xp.where(bad, jj + 1, self.last_x), xp.where(bad, jj, self.last_u)   # the failing state stays logged
+        self.collided = self.collided | bad
+        self.alive = self.alive & ~bad
+        self.x_cur = xp.where(self.alive[:, None], x_next, self.x_cur)
+        xp.step_advance(self._jt)
+
+    def _run_half(self, half, fn, j):
+        """eager for the first steps (workspaces get allocated), then captured once per code path and replayed"""
+        key = (half, self._ever_aborted)
+        g = self._graphs.get(key)
+        if g is None and self._use_graphs and j >= 3 and key not in self._graphs:
+            import torch
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=torch.cuda.current_stream(), capture_error_mode='relaxed'):
+                    fn()                  # (capturing records the launches without executing them)
+                self._graphs[key] = g
+            except Exception as e:        # report once, stay eager
+                print(f'[run_mpc] hipGraph capture of step half {half} failed ({type(e).__name__}: {e}); eager launches')
+                self._graphs[key], self._use_graphs, g = None, False, None
+        if g is not None:
+            g.replay()
+        else:
+            fn()
+
+    def run(self):
+        """generator: yields once per step, after the first half is enqueued (run_mpc serves the other groups meanwhile)"""
+        xp = self._xp
+        for j in range(self._n_steps):
+            self._run_half('a', self.part_a, j)
+            yield j
+            self.handle_aborts()
+            self._run_half('b', self.part_b, j)
+            if self._callback and j % 50 == 0:
+                print(f'step {j} (instances {self._first}..{self._first + self._B - 1}): alive {int(xp.host(self.alive).sum())}/{self._B}, '
+                      f'in abort {int(xp.host(self.sa & self.alive).sum())}, failures {int(xp.host(self.collided).sum())}')
+            if not xp.on_device and not self.alive.any():
+                break
+
+    def results(self):
+        xp, ctrl, params, B, n_steps = self._xp, self._ctrl, self._params, self._B, self._n_steps
+        solver, pr = ctrl.ocp_solver, ctrl.problem
+        if xp.on_device:
+            solver.sync()
+        # convergence at the last step (mpc.py:273): the reference tests x_sim[-1], NaN for instances that broke
+        x_sim = np.ascontiguousarray(np.transpose(xp.host(self.x_log), (1, 0, 2)))
+        u_sim = np.ascontiguousarray(np.transpose(xp.host(self.u_log), (1, 0, 2)))
+        steps = np.arange(n_steps + 1)[None, :]
+        x_sim[steps > xp.host(self.last_x)[:, None]] = np.nan
+        u_sim[steps[:, :n_steps] > xp.host(self.last_u)[:, None]] = np.nan
+        x_last = np.nan_to_num(x_sim[:, -1])
+        ev = solver.eval_nodes(xp.repeat_nodes(xp.asarray(x_last, xp.f64), ctrl.N + 1), xp.zeros((B, ctrl.N, ctrl.nu)), ctrl.p)
+        ee = xp.host(ev['ee'])[:, 0, :]
+        conv = xp.host(self.alive) & ~np.isnan(x_sim[:, -1]).any(1) & (np.linalg.norm(ee - pr.ee_ref, axis=1) < params.tol_conv)
+        return dict(x=x_sim, u=u_sim, r_receding=np.transpose(xp.host(self.r_log), (1, 0))[:, :, None], conv=conv,
+                    collided=xp.host(self.collided), viable=xp.host(self.viable), abort_events=self._abort_events)
 
 
 def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, make_controller=None, make_backup=None,
-            n_steps=None, callback=False, on_device=False, device=0, timing=None, groups=None):
+            n_steps=None, callback=False, on_device=False, device=0, timing=None, groups=None, graphs=True):
     """scripts/mpc.py:102-317 for all instances at once.  Returns the result dict the reference pickles (mpc.py:307-315).
 
     ``on_device=True``: the whole loop state -- the policy automaton of the controller, the safe-abort automaton of the driver
@@ -368,9 +424,10 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
     and every engine call takes the device-pointer path.  The only host synchronisation inside a step is one scalar per
     group for the policies that can abort: "did any instance raise abort in this step?" (the backup OCP is solved only then,
     as in the reference, mpc.py:161-190, and only for the aborting instances).  The instances are split into ``groups``
-    independent sub-batches (default 3 on the device), each with its own engine handle and HIP stream, advanced in turn:
+    independent sub-batches (default 2 on the device), each with its own engine handle and HIP stream, advanced in turn:
     while the host waits for one group's flag the others' kernels keep the GPU busy, and the long tail of one group's QP
-    launch overlaps the bulk of another's.  ``timing``: optional dict that receives wall-clock ms per step of the loop."""
+    launch overlaps the bulk of another's.  With ``graphs`` each half of a step (before / after that flag) is captured as a
+    hipGraph after a few eager steps and replayed.  ``timing``: optional dict that receives wall-clock ms per step."""
     import time
     B = x_guess.shape[0]
     n_steps = int(n_steps if n_steps is not None else params.n_steps)
@@ -381,23 +438,24 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
         make_controller = make_controller or (lambda name, batch: get_controller(name, params, batch))
         make_backup = make_backup or (lambda batch: SafeBackupController(params, batch))
     if groups is None:
-        groups = max(1, min(3, B // 512)) if on_device else 1
+        groups = max(1, min(2, B // 512)) if on_device else 1      # measured at B = 4096 (MI355X, r2): 1: 5.1, 2: 4.55, 3: 5.8 ms/step
     from .sharding import shard_range
     spans = [shard_range(B, groups, g) for g in range(groups)]
-    gens, outs, streams = [], [], []
+    gens, grps, streams = [], [], []
     for lo, hi in spans:
         ctrl = make_controller(cont_name, hi - lo)
         backup = make_backup(hi - lo)
-        out = {}
-        outs.append(out)
-        gens.append(_group_loop(params, cont_name, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo,
-                                callback, out))
         if on_device:
             import torch
             sv = ctrl.ocp_solver
             streams.append(torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=torch.device('cuda', sv.device)))
+            with torch.cuda.stream(streams[-1]):
+                grp = _Group(params, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo, callback, graphs)
         else:
             streams.append(None)
+            grp = _Group(params, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo, callback, False)
+        grps.append(grp)
+        gens.append(grp.run())
 
     def advance(g):
         """runs group g up to its next yield (end of the enqueue phase of a step); False once the group is finished"""
@@ -426,11 +484,22 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
                 torch.cuda.synchronize()
             t_loop, j_loop = time.perf_counter(), j
     if timing is not None:
+        if on_device:
+            import torch
+            torch.cuda.synchronize()
         done = max(n_steps + 1 - j_loop, 1)
         timing['ms_per_step'] = 1e3 * (time.perf_counter() - t_loop) / done
         timing['steps'], timing['groups'] = done, groups
 
     # merge the groups (global instance indices)
+    outs = []
+    for g, grp in enumerate(grps):
+        if streams[g] is not None:
+            import torch
+            with torch.cuda.stream(streams[g]):
+                outs.append(grp.results())
+        else:
+            outs.append(grp.results())
     x_sim = np.concatenate([o['x'] for o in outs], axis=0)
     conv = np.concatenate([o['conv'] for o in outs])
     collided = np.concatenate([o['collided'] for o in outs])

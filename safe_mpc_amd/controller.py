@@ -14,12 +14,12 @@ from __future__ import annotations
 
 import numpy as np
 
-from ._xp import NumpyOps, TorchOps
+from ._xp import InPlaceState, NumpyOps, TorchOps
 from .problem import OcpProblem
 from .safe_set import SafeSetNet
 
 
-class AbstractController:
+class AbstractController(InPlaceState):
     """``device_state=True`` keeps every per-instance array of the policy (guesses, counters, receding indices, viable states,
     per-node parameters) as ROCm torch tensors and drives the engine through its device-pointer path: ``step`` then enqueues
     kernels only -- no array crosses PCIe and nothing synchronises with the host.  The default (numpy) is the host path."""
@@ -47,8 +47,10 @@ class AbstractController:
         xp = self.xp
         self._x_min, self._x_max = xp.asarray(self.problem.x_min, xp.f64), xp.asarray(self.problem.x_max, xp.f64)
         self._tau_min, self._tau_max = xp.asarray(self.problem.tau_min, xp.f64), xp.asarray(self.problem.tau_max, xp.f64)
+        self._lbx_e, self._ubx_e = xp.asarray(self.problem.lbx_e, xp.f64), xp.asarray(self.problem.ubx_e, xp.f64)
         self._alloc()
         self.reset_controller()
+        self._inplace = bool(device_state)       # device mode: state arrays keep their addresses (see _xp.InPlaceState)
 
     # -- state --------------------------------------------------------------------------------------------------------
     def _alloc(self):
@@ -104,13 +106,13 @@ class AbstractController:
         self.p[:, :, 3] = self.params.alpha
         if not self.xp.on_device:
             x0 = np.asarray(x0, float)
+        if self.xp.on_device:     # the engine writes straight into the controller's persistent buffers
+            self.ocp_solver.solve(x0, self.x_guess, self.u_guess, self.p, out=(self.x_temp, self.u_temp, self.last_status, self.qp_iter))
+            return self.last_status
         x, u, st, it = self.ocp_solver.solve(x0, self.x_guess, self.u_guess, self.p)
-        if self.xp.on_device:
-            self.x_temp, self.u_temp, self.last_status, self.qp_iter = x, u, st, it
-        else:
-            self.x_temp, self.u_temp = np.asarray(x), np.asarray(u)
-            self.last_status = np.asarray(st).copy()
-            self.qp_iter = np.asarray(it).copy()
+        self.x_temp, self.u_temp = np.asarray(x), np.asarray(u)
+        self.last_status = np.asarray(st).copy()
+        self.qp_iter = np.asarray(it).copy()
         return self.last_status
 
     def guessCorrection(self):
@@ -315,8 +317,8 @@ class RealReceding(RecedingController):
         # other nodes: the model bounds (:534-536); the terminal node keeps lbx_e / ubx_e
         k = xp.arange(N + 1)[None, :, None]
         last = k == N
-        lo = xp.where(last, xp.asarray(pr.lbx_e, xp.f64)[None, None, :], self._x_min[None, None, :])
-        hi = xp.where(last, xp.asarray(pr.ubx_e, xp.f64)[None, None, :], self._x_max[None, None, :])
+        lo = xp.where(last, self._lbx_e[None, None, :], self._x_min[None, None, :])
+        hi = xp.where(last, self._ubx_e[None, None, :], self._x_max[None, None, :])
         sel = self.r < N
         centre = xp.take_rows(self.x_guess, xp.clip_max(self.r, N - 1) + 1)[:, None, :]     # x_guess[b, r_b + 1]
         at_r = (k == self.r[:, None, None]) & sel[:, None, None]

@@ -33,7 +33,8 @@ def main():
             tm = {}
             t0 = time.perf_counter()
             res = cl.run_mpc(par, name, xg, ug, n_steps=steps, on_device=dev, timing=tm,
-                             groups=int(os.environ['SMPC_GROUPS']) if 'SMPC_GROUPS' in os.environ else None)
+                             groups=int(os.environ['SMPC_GROUPS']) if 'SMPC_GROUPS' in os.environ else None,
+                             graphs=os.environ.get('SMPC_GRAPHS', '1') != '0')
             print(f"{name:12s} {'device' if dev else 'host  '} state: {tm['ms_per_step']:.3f} ms/step over {tm['steps']} steps "
                   f"(B={B}, N={N}, groups {tm.get('groups')}; total {time.perf_counter() - t0:.1f} s incl. set-up) | collisions {len(res['collisions_idx'])} "
                   f"viable {len(res['viable_idx'])} converged {len(res['conv_idx'])}", flush=True)
