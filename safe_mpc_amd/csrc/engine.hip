@@ -874,6 +874,36 @@ int smpc_get_qp_wave_stats(smpc_handle* h, double* out3) {
 
 }  // extern "C"
 
+// Diagnostic entry (not part of include/smpc.h): times k_node_torque with its outputs in the node records (mode 0) or field-major
+// across the batch axis (mode 1) on device-resident xg / ug; ms = average of `reps` launches.
+extern "C" int smpc_debug_torque_layout(smpc_handle* h, int B, const double* xg, const double* ug, int mode, int reps, float* ms) {
+    if (!h || h->desc.nq != 6) return SMPC_EINVAL;
+    (void)hipSetDevice(h->device);
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    const long n = (long)B * h->N;
+    double* soa = nullptr;
+    if (mode == 1 && hipMalloc((void**)&soa, sizeof(double) * n * (6 + 3 * 36)) != hipSuccess) return SMPC_ENOMEM;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int i = 0; i < reps + 1; i++) {
+        if (i == 1) (void)hipEventRecord(e0, h->stream);
+        if (mode == 0)
+            hipLaunchKernelGGL((k_node_torque<6>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_desc, B, h->N, xg, ug, h->d_ev);
+        else
+            hipLaunchKernelGGL((k_node_torque_soa<6>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_desc, B, h->N, xg, ug, soa);
+    }
+    (void)hipEventRecord(e1, h->stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(ms, e0, e1);
+    *ms /= (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (soa) (void)hipFree(soa);
+    return SMPC_OK;
+}
+
 #ifdef QP_PROFILE
 // diagnostic builds only (not part of include/smpc.h): per-phase shader-clock sums of k_qp_ipm since the last call
 extern "C" int smpc_debug_qp_profile(unsigned long long* out16) {

@@ -145,4 +145,31 @@ __global__ __launch_bounds__(64) void k_node_torque(const smpc_problem_desc* __r
     rd::rnea_with_derivatives<NQ>(D->joints, D->gravity, q, qd, qdd, o->tau, o->M, o->dtau_dq, o->dtau_dv);
 }
 
+// Layout experiment (diagnostic entry smpc_debug_torque_layout): the same work with the outputs written
+// field-major across the batch axis -- out[f][node], consecutive lanes to consecutive addresses -- instead of into each node's
+// 2.6 KB record.
+template <int NQ>
+__global__ __launch_bounds__(64) void k_node_torque_soa(const smpc_problem_desc* __restrict__ D, int B, int N,
+                                                        const double* __restrict__ xg, const double* __restrict__ ug,
+                                                        double* __restrict__ out) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)B * N;
+    if (t >= n) return;
+    constexpr int NX = 2 * NQ;
+    const long b = t / N;
+    const int k = (int)(t % N);
+    const double* x = xg + (b * (N + 1) + k) * NX;
+    const double* u = ug + t * NQ;
+    double q[NQ], qd[NQ], qdd[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        q[i] = x[i];
+        qd[i] = x[NQ + i];
+        qdd[i] = u[i];
+    }
+    double* o = out + t;
+    rd::rnea_with_derivatives<NQ>(D->joints, D->gravity, q, qd, qdd, o, o + (long)NQ * n, o + (long)(NQ + NQ * NQ) * n,
+                                  o + (long)(NQ + 2 * NQ * NQ) * n, n);
+}
+
 }  // namespace smpc

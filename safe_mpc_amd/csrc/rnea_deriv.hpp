@@ -92,9 +92,10 @@ SMPC_FN V3 rot(const double* R, const double* v) {
 }
 
 // tau[NQ]; M, dq, dv row-major NQ x NQ with leading dimension NQ:  M[j*NQ+k] = d tau_j / d qdd_k, dq[..] = d tau_j / d q_k, ...
+// es: element stride of the four outputs (1: packed as above; the layout experiment of DESIGN.md section 4 passes the node count)
 template <int NQ>
 SMPC_FN void rnea_with_derivatives(const smpc_joint* J, const double* grav, const double* q, const double* qd,
-                                   const double* qdd, double* tau, double* M, double* dq, double* dv) {
+                                   const double* qdd, double* tau, double* M, double* dq, double* dv, long es = 1) {
     SV S[NQ], v[NQ], a[NQ];
     Inertia Y[NQ];
     // ---- forward: kinematics and body inertias in world coordinates ---------------------------------------------------
@@ -176,7 +177,7 @@ SMPC_FN void rnea_with_derivatives(const smpc_joint* J, const double* grav, cons
             Bc[0 * 6 + c] += col.a.x; Bc[1 * 6 + c] += col.a.y; Bc[2 * 6 + c] += col.a.z;
             Bc[3 * 6 + c] += col.l.x; Bc[4 * 6 + c] += col.l.y; Bc[5 * 6 + c] += col.l.z;
         }
-        tau[m] = mdotf(S[m], F);
+        tau[m * es] = mdotf(S[m], F);
 #pragma unroll
         for (int k = 0; k <= m; k++) {
             const SV Sk = S[k];
@@ -186,17 +187,17 @@ SMPC_FN void rnea_with_derivatives(const smpc_joint* J, const double* grav, cons
             const SV cv = applyB(Sk) + apply(Yc, psi) * 2.0;
             SV dd = applyB(psi) + apply(Yc, chi);
             const double mm = mdotf(S[m], yS);
-            M[m * NQ + k] = mm;
-            M[k * NQ + m] = mm;
+            M[(m * NQ + k) * es] = mm;
+            M[(k * NQ + m) * es] = mm;
             if (k < m) {
-                dv[m * NQ + k] = mdotf(S[m], cv);
-                dq[m * NQ + k] = mdotf(S[m], dd);
+                dv[(m * NQ + k) * es] = mdotf(S[m], cv);
+                dq[(m * NQ + k) * es] = mdotf(S[m], dd);
             } else {
                 dd = dd + mxf(Sk, F);
 #pragma unroll
                 for (int j = 0; j <= m; j++) {
-                    dv[j * NQ + m] = mdotf(S[j], cv);
-                    dq[j * NQ + m] = mdotf(S[j], dd);
+                    dv[(j * NQ + m) * es] = mdotf(S[j], cv);
+                    dq[(j * NQ + m) * es] = mdotf(S[j], dd);
                 }
             }
         }
