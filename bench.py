@@ -12,7 +12,8 @@ Workload (config.workload = "C1"): Z1-class 6-DoF, N = 30, 4096 OCP instances pe
 Halton initial states, constant first guess -- SURVEY 8(d).
   --scaling weak   (default) every rank owns 4096 instances
   --scaling strong 4096 instances in total, split over the ranks by shard_range (the north star's wording)
-The only exchange is one RCCL gather of the applied controls + statuses per step.
+The only exchange is ONE RCCL gather of the rollout log (applied controls + statuses of every timed step) at the end of the
+timed region.
 
 Launch: `python bench.py --gpus N` starts N fresh child processes itself (one per GPU, before anything touches a GPU) when
 no launcher environment is present; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it
@@ -227,10 +228,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     use_dist = world > 1 or os.environ.get('SMPC_FORCE_DIST') == '1'      # the env knob exercises the RCCL path with one rank
+    init_only = os.environ.get('SMPC_DIST_INIT_ONLY') == '1'             # diagnostic: communicator up, no per-step exchange
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    if init_only:
+        use_dist = False
 
     from safe_mpc_amd.sharding import gather_to_root, shard_range
     from safe_mpc_amd.solver import BatchedOcpSolver
@@ -272,9 +276,14 @@ def main():
                       torch.empty(sb.n, dtype=torch.int32, device=dev))
             sb.iters = torch.zeros((), dtype=torch.float64, device=dev)
             sb.fails = torch.zeros((), dtype=torch.float64, device=dev)
-            sb.payload = torch.empty((sb.n, nu + 1), dtype=torch.float64, device=dev)
+            sb.off = lo
         subs.append(sb)
-    gather_in = torch.empty((B, nu + 1), dtype=torch.float64, device=dev)
+    # Results for rank 0: every sub-batch writes [u_apply | status] of each step into its slice of a rollout log; ONE gather of
+    # the log at the end of the timed steps ("once per step ... or once per rollout").  A per-step collective would
+    # need an event hand-off between the sub-batch streams and the collective's stream every step; measured on one GPU that
+    # re-synchronises the streams and costs 0.5-1.5 ms of the 3.9 ms step even with the collective itself skipped.
+    K_log = max(args.steps, 1)
+    gather_in = torch.empty((K_log, B, nu + 1), dtype=torch.float64, device=dev)
     if args.scaling == 'strong':
         sizes_all = [shard_range(args.batch, world, r)[1] - shard_range(args.batch, world, r)[0] for r in range(world)]
     else:
@@ -283,7 +292,7 @@ def main():
     gather_bufs = None
     if use_dist:
         from safe_mpc_amd.sharding import gather_buffers
-        gather_bufs = gather_buffers(gather_in, sizes_all, rank)
+        gather_bufs = gather_buffers(gather_in.view(K_log * B, nu + 1), [K_log * n_r for n_r in sizes_all], rank)
 
     def sub_step(sb, first):
         """One closed-loop step of one sub-batch, entirely on its stream, state updated in place (graph-capturable)."""
@@ -298,8 +307,11 @@ def main():
         sb.iters.add_(it.sum())
         sb.fails.add_((st != 0).sum())
         if use_dist:
-            sb.payload[:, :nu] = u_apply
-            sb.payload[:, nu] = st.to(torch.float64)
+            pay = gather_in[step_no[0] % K_log, sb.off:sb.off + sb.n]
+            pay[:, :nu] = u_apply
+            pay[:, nu] = st.to(torch.float64)
+
+    step_no = [0]
 
     def step(first):
         for sb in subs:
@@ -308,19 +320,15 @@ def main():
                     sb.graph.replay()       # the ~25 launches of one sub-batch step as ONE hipGraphLaunch
                 else:
                     sub_step(sb, first)
-        if use_dist:                                                                  # the single result gather
-            # stream-ordered, no host synchronisation: the gather stream waits for the sub-batches, and they wait for the
-            # copy out of their payload buffers before the next step overwrites them
-            cur = torch.cuda.current_stream()
-            for sb in subs:
-                cur.wait_stream(sb.stream)
-            off = 0
-            for sb in subs:
-                gather_in[off:off + sb.n] = sb.payload
-                off += sb.n
-            for sb in subs:
-                sb.stream.wait_stream(cur)
-            gather_to_root(gather_in, sizes=sizes_all, bufs=gather_bufs, concat=False)
+        step_no[0] += 1
+
+    def gather_results():
+        """the single result gather, inside the timed region: the rollout log of this rank's instances to rank 0"""
+        cur = torch.cuda.current_stream()
+        for sb in subs:
+            cur.wait_stream(sb.stream)
+        if os.environ.get('SMPC_SKIP_NCCL') != '1':      # (diagnostic knob: everything but the collective itself)
+            gather_to_root(gather_in.view(K_log * B, nu + 1), sizes=[K_log * n_r for n_r in sizes_all], bufs=gather_bufs, concat=False)
 
     def barrier():
         for sb in subs:
@@ -338,7 +346,7 @@ def main():
     # hipGraph capture of one sub-batch step (after the warm-up: every workspace exists, nothing allocates or syncs).
     # With S sub-batches in flight the host has to issue S x 25 launches per step; as graphs that is S launches, and the
     # streams drift apart so that the long tail of one sub-batch's QP kernel is filled by the bulk of another's.
-    if args.graphs and args.warmup >= 2:
+    if args.graphs and args.warmup >= 2 and not use_dist:      # (the captured step bakes in one slot of the rollout log)
         try:
             for sb in subs:
                 g = torch.cuda.CUDAGraph()
@@ -355,8 +363,11 @@ def main():
         sb.fails.zero_()
     barrier()
     t0 = time.perf_counter()
+    step_no[0] = 0
     for i in range(args.steps):
         step(first=(args.warmup == 0 and i == 0))
+    if use_dist:
+        gather_results()
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
