@@ -464,3 +464,34 @@ def test_generate_guess_merit_backtracking_on_engine():
     ctrl = C.get_controller('htwa', par, int(good.sum()))
     ctrl.x_temp, ctrl.u_temp = guess['xg'].copy(), guess['ug'].copy()
     assert np.all(ctrl.checkGuess())
+
+
+def test_rollout_sub_batch_workers_change_nothing(monkeypatch):
+    """smpc_rollout_batch splits a large batch into sub-batches on their own streams (worker handles borrowing the network
+    weights): instances are independent, so the trajectories are the same bits whatever the split -- host and device pointers,
+    per-instance plants and per-step torque noise included."""
+    import torch
+    from safe_mpc_amd import closed_loop as cl
+    par, prob, net = make_problem('st', 'ext', N=12)
+    s = _solver(prob, net)
+    B, n = 50, 5
+    x0 = sample_instances(prob, B, seed=21, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0)
+    noise = 0.05 * np.random.default_rng(4).standard_normal((n, B, 6))
+    jt = cl.perturbed_joint_tables(par, 6, 5.0, np.arange(B))
+    monkeypatch.setenv('SMPC_ROLLOUT_STREAMS', '1')
+    ref = s.rollout(x0, xg, ug, p, n, joints_noisy=jt, tau_noise=noise)
+    for streams in ('3', '7'):
+        monkeypatch.setenv('SMPC_ROLLOUT_STREAMS', streams)
+        got = s.rollout(x0, xg, ug, p, n, joints_noisy=jt, tau_noise=noise)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), streams
+    dev = torch.device('cuda:0')
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    xgd, ugd = t(xg), t(ug)
+    jtd = torch.tensor(np.ascontiguousarray(jt).view(np.float64).reshape(B, 6, -1), device=dev)
+    got = s.rollout(t(x0), xgd, ugd, t(p), n, joints_noisy=jtd, tau_noise=t(noise))
+    s.sync()
+    for a, b in zip(ref[:3], got[:3]):
+        assert np.array_equal(a, b.cpu().numpy())
+    assert np.array_equal(ref[4], xgd.cpu().numpy())
