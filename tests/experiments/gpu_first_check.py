@@ -1,7 +1,7 @@
 """First GPU bring-up check: component-by-component parity print-out (diagnostic, not a test)."""
 import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np
 from conftest import constant_guess, make_problem, sample_instances
 from oracle.oracle import Oracle

@@ -1,5 +1,5 @@
 """CPU experiment (oracle only, not product): closed-loop C1 iteration statistics of the IPM under descriptor options.
-usage: python scripts/experiments/ipm_cpu_sweep.py [B] [steps]"""
+usage: python tests/experiments/ipm_cpu_sweep.py [B] [steps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
