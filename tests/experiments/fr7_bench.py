@@ -1,4 +1,8 @@
-import sys; sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+"""C4-like timing (7-DoF, N = 40, safe-set row on every node, B = 4096, first step from the constant guess); starts sampled
+with the test helpers (tests/conftest.py), hence under tests/."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np, torch
 from conftest import *
 from safe_mpc_amd.solver import BatchedOcpSolver

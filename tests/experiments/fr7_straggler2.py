@@ -1,4 +1,4 @@
-"""CPU experiment (oracle only): scripts/fr7_bench.py's workload (vel_scale 0.1), slowest instance traced."""
+"""CPU experiment (oracle only): tests/experiments/fr7_bench.py's workload (vel_scale 0.1), slowest instance traced."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
