@@ -89,8 +89,10 @@ class Parameters:
         self.links = [l.name for l in self.robot_descr.links]
         self.joints = list(self.robot_descr.joints)
 
-        self.test_num = int(cfg['test_num'])
-        self.n_steps = int(cfg['n_steps'])
+        # (environment overrides of sizes and of the data directory: quick runs and tests without editing config.yaml)
+        self.DATA_DIR = os.path.join(os.environ.get('SMPC_DATA_DIR', self.DATA_DIR), '')
+        self.test_num = int(os.environ.get('SMPC_TEST_NUM', cfg['test_num']))
+        self.n_steps = int(os.environ.get('SMPC_N_STEPS', cfg['n_steps']))
         self.cpu_num = int(cfg['cpu_num'])
         self.build = False
 

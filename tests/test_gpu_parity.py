@@ -495,3 +495,38 @@ def test_rollout_sub_batch_workers_change_nothing(monkeypatch):
     for a, b in zip(ref[:3], got[:3]):
         assert np.array_equal(a, b.cpu().numpy())
     assert np.array_equal(ref[4], xgd.cpu().numpy())
+
+
+def test_entry_scripts_end_to_end(tmp_path, monkeypatch):
+    """The reference's two live entry points, same flags and file names: scripts/guess_acados.py writes the
+    warm-start pickle {'xg','ug'} that scripts/mpc.py loads (mpc.py:79-84); mpc.py runs the closed loop with all state on the
+    device and writes the result pickle (mpc.py:307-315); its exit code is the number of failed instances (mpc.py:317)."""
+    import importlib.util
+    import os
+    import pickle
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setenv('SMPC_DATA_DIR', str(tmp_path))
+    monkeypatch.setenv('SMPC_TEST_NUM', '12')
+    monkeypatch.setenv('SMPC_N_STEPS', '25')
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, 'scripts', name + '.py'))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    argv = ['-c', 'htwa', '--horizon', '12', '--alpha', '10']
+    assert load('guess_acados').main(argv) == 0
+    gfile = [f for f in os.listdir(tmp_path) if f.endswith('_guess.pkl')]
+    assert gfile == ['z1_htwa_12hor_10sm_use_netTrue__q_collision_margins_0.0_0.0_guess.pkl']
+    g = pickle.load(open(os.path.join(tmp_path, gfile[0]), 'rb'))
+    n = g['xg'].shape[0]
+    assert 1 <= n <= 12 and g['xg'].shape[1:] == (13, g['xg'].shape[2]) and g['ug'].shape[:2] == (n, 12)
+    rc = load('mpc').main(argv)
+    rfile = [f for f in os.listdir(tmp_path) if f.endswith('_mpc.pkl')]
+    assert rfile == ['z1_htwa_use_netTrue_12hor_10sm_noise_0.0_control_noise0.0_q_collision_margins_0.0_0.0_mpc.pkl']
+    res = pickle.load(open(os.path.join(tmp_path, rfile[0]), 'rb'))
+    assert set(res) >= {'x', 'u', 'r', 'conv_idx', 'collisions_idx', 'unconv_idx', 'viable_idx', 'x_viable'}
+    assert res['x'].shape == (n, 26, g['xg'].shape[2]) and res['u'].shape[:2] == (n, 25)
+    assert rc == len(res['collisions_idx'])
+    parts = set(res['conv_idx']) | set(res['collisions_idx']) | set(res['unconv_idx']) | set(res['viable_idx'])
+    assert parts == set(range(n))
