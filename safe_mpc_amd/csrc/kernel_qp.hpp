@@ -111,6 +111,34 @@ template <int NQ> struct QpLayout {
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
+// Cache policy of the stage-workspace accesses, selectable at build time (-DSMPC_NT_MASK=...).  The workspace is a stream:
+// every block is touched once per sweep by one wavefront and comes round again a millisecond later, long after the 4 MB L2
+// of its XCD has turned over, so non-temporal (`nt`) accesses look right -- and for ONE launch over the whole batch they are:
+// nt on the wide loads and on the factorisation sweep's wide stores (mask 0x3) takes 8.5 % off k_qp_ipm (2.85 -> 2.62 ms at 5
+// forced iterations, A/B in one session; narrow 8-byte nt loads +6 %, k_qp_setup's stores no gain).  In the closed-loop
+// bench, where three sub-batch launches and their linearisation / set-up kernels share the chip, the same build is 4 %
+// SLOWER (4.02 vs 3.86 ms per step, three alternations) -- the sub-batch workspaces (278 MB each) partly live in the
+// 256 MB Infinity Cache between a set-up and its first sweeps, and nt gives that up.  Shipped default: 0 (plain accesses).
+#ifndef SMPC_NT_MASK
+#define SMPC_NT_MASK 0x0
+#endif
+template <int BIT, class T> __device__ __forceinline__ T ld_ws(const T* p) {
+    if constexpr ((SMPC_NT_MASK >> BIT) & 1) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <int BIT, class T> __device__ __forceinline__ void st_ws(T v, T* p) {
+    if constexpr ((SMPC_NT_MASK >> BIT) & 1) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+// bit 0: wide loads of k_qp_ipm (pieces, row pairs)   bit 1: wide stores of the factorisation sweep (t, lambda, factor block)
+// bit 2: narrow loads of k_qp_ipm                     bit 3: narrow stores of k_qp_ipm      bit 4: k_qp_setup (record load, stores)
+template <class T> __device__ __forceinline__ T ldnt(const T* p) { return ld_ws<0>(p); }
+template <class T> __device__ __forceinline__ void stnt_b1(T v, T* p) { st_ws<1>(v, p); }
+template <class T> __device__ __forceinline__ T ldnt_s(const T* p) { return ld_ws<2>(p); }
+template <class T> __device__ __forceinline__ void stnt_s(T v, T* p) { st_ws<3>(v, p); }
+template <class T> __device__ __forceinline__ T ldnt_su(const T* p) { return ld_ws<4>(p); }
+template <class T> __device__ __forceinline__ void stnt_su(T v, T* p) { st_ws<4>(v, p); }
+
 // wave-local hand-off through LDS: LDS operations of one wave execute in issue order, so all that is needed is that the
 // compiler neither reorders nor caches them across this point
 __device__ __forceinline__ void lds_fence() {
@@ -309,7 +337,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
     {
         const dbl2* s2 = reinterpret_cast<const dbl2*>(ev + (size_t)b * (N + 1) + k);
         dbl2* d2 = reinterpret_cast<dbl2*>(sEV);
-        for (int i = hl; i < EV_D / 2; i += 32) d2[i] = s2[i];
+        for (int i = hl; i < EV_D / 2; i += 32) d2[i] = ldnt_su(s2 + i);
     }
     // z = 0 except the fixed dx_0
     sZ0[hl] = (k == 0 && hl >= NU && hl < NZ) ? x0[(size_t)b * NX + hl - NU] - xk[hl - NU] : 0.0;
@@ -389,28 +417,28 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
             const int t = el - NQ * NZP, r = t / NQP, ix = t - r * NQP;
             src = ix < NQ ? (NQ + r) * NZP + NU + ix : -1;
         } else src = (NQ + MR) * NZP + NU + (el - NQ * NZP - MR * NQP);
-        w[Ly.oC + el] = src >= 0 ? sC[src] : 0.0;
+        stnt_su(src >= 0 ? sC[src] : 0.0, w + Ly.oC + el);
     }
-    if (hl < NRT) { w[Ly.oR0 + 2 * hl] = sLO[hl]; w[Ly.oR0 + 2 * hl + 1] = sHI[hl]; }
+    if (hl < NRT) stnt_su(dbl2{sLO[hl], sHI[hl]}, reinterpret_cast<dbl2*>(w + Ly.oR0) + hl);
     double* img = w + Ly.oIMG;
     for (int el = hl; el < NZ * NQP; el += 32) {
         const int c = el / NQP, r = el - c * NQP;
-        img[Ly.iTT + el] = r < NQ ? sC[r * NZP + c] : 0.0;
+        stnt_su(r < NQ ? sC[r * NZP + c] : 0.0, img + Ly.iTT + el);
     }
     for (int el = hl; el < NQ * MRP; el += 32) {
         const int ix = el / MRP, r = el - ix * MRP;
-        img[Ly.iGT + el] = r < MR ? sC[(NQ + r) * NZP + NU + ix] : 0.0;
+        stnt_su(r < MR ? sC[(NQ + r) * NZP + NU + ix] : 0.0, img + Ly.iGT + el);
     }
-    if (hl < NX) img[Ly.iGN + hl] = sC[(NQ + MR) * NZP + NU + hl];
+    if (hl < NX) stnt_su(sC[(NQ + MR) * NZP + NU + hl], img + Ly.iGN + hl);
     for (int el = hl; el < qp_even_c(NQ * NQ); el += 32) {
         const int i = el / NQ, j = el - i * NQ;
-        img[Ly.iHQQ + el] = el < NQ * NQ ? (reach ? cs * e.cost_hess_qq[el] : 0.0) + (i == j ? lm : 0.0) : 0.0;
+        stnt_su(el < NQ * NQ ? (reach ? cs * e.cost_hess_qq[el] : 0.0) + (i == j ? lm : 0.0) : 0.0, img + Ly.iHQQ + el);
     }
-    if (hl < NZP) img[Ly.iGZ + hl] = sGZ[hl];
-    if (hl < NX) img[Ly.iB + hl] = sB[hl];
+    if (hl < NZP) stnt_su(sGZ[hl], img + Ly.iGZ + hl);
+    if (hl < NX) stnt_su(sB[hl], img + Ly.iB + hl);
     if (hl < 4) {
         const double huu = (reach && !last ? cs * 2.0 * D->R : 0.0) + lm;
-        img[Ly.iSC + hl] = hl == 0 ? huu : (hl == 1 ? lm : (hl == 2 ? wsoft : bflag));
+        stnt_su(hl == 0 ? huu : (hl == 1 ? lm : (hl == 2 ? wsoft : bflag)), img + Ly.iSC + hl);
     }
 
     // ---- initial slacks / multipliers ----------------------------------------------------------------------------------
@@ -457,16 +485,16 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
             }
         }
         if (r < NRT) {
-            w[Ly.oR1 + 2 * r] = tl; w[Ly.oR1 + 2 * r + 1] = tu;
-            w[Ly.oR2 + 2 * r] = ll; w[Ly.oR2 + 2 * r + 1] = lu;
-            w[Ly.oR3 + 2 * r] = 0.0; w[Ly.oR3 + 2 * r + 1] = 0.0;
+            stnt_su(dbl2{tl, tu}, reinterpret_cast<dbl2*>(w + Ly.oR1) + r);
+            stnt_su(dbl2{ll, lu}, reinterpret_cast<dbl2*>(w + Ly.oR2) + r);
+            stnt_su(dbl2{0.0, 0.0}, reinterpret_cast<dbl2*>(w + Ly.oR3) + r);
         }
         sE[r] = -(ll - lu);
     }
-    if (hl < 2) w[Ly.oSL + hl] = hl == 0 ? wsoft : bflag;
-    if (hl < NX) { w[Ly.oAUX + 2 * hl] = sB[hl]; w[Ly.oAUX + 2 * hl + 1] = wsoft; }
-    if (hl < NZ) { w[Ly.oZ + hl] = sZ0[hl]; w[Ly.oZN + hl] = sZ0[hl]; }
-    if (hl < NX) w[Ly.oPB + hl] = 0.0;
+    if (hl < 2) stnt_su(hl == 0 ? wsoft : bflag, w + Ly.oSL + hl);
+    if (hl < NX) stnt_su(dbl2{sB[hl], wsoft}, reinterpret_cast<dbl2*>(w + Ly.oAUX) + hl);
+    if (hl < NZ) { stnt_su(sZ0[hl], w + Ly.oZ + hl); stnt_su(sZ0[hl], w + Ly.oZN + hl); }
+    if (hl < NX) stnt_su(0.0, w + Ly.oPB + hl);
     lds_fence();
     // stationarity residual at the initial point (pi = 0): g - C^T (ll - lu); dx_0 does not enter (no cost cross term)
     if (hl < NZ && !(k == 0 && hl >= NU) && !(last && hl < NU)) {
@@ -696,14 +724,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 const double* w = stage_ptr(k);
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
 #pragma unroll
-                for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
-                const dbl2 r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr], r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr],
-                           r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr], r3 = reinterpret_cast<const dbl2*>(w + Ly.oR3)[hr];
+                for (int j = 0; j < IMG_PF; j++) img[j] = ldnt(s2 + min(hl + 32 * j, img_n2 - 1));
+                const dbl2 r0 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR0) + hr), r1 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR1) + hr),
+                           r2 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR2) + hr), r3 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR3) + hr);
                 rs.lo = r0.x; rs.hi = r0.y; rs.tl = r1.x; rs.tu = r1.y; rs.ll = r2.x; rs.lu = r2.y;
                 czar = r3.x; cznr = r3.y;
-                slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                zc = w[Ly.oZ + hz];
-                znc = w[Ly.oZN + hz];
+                slb = ldnt_s(reinterpret_cast<const dbl2*>(w + Ly.oSL));
+                zc = ldnt_s(w + Ly.oZ + hz);
+                znc = ldnt_s(w + Ly.oZN + hz);
             };
             auto stage_b1 = [&](int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
@@ -724,15 +752,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     const QpDir rd = qp_row_dir<false>(rs, soft, wsoft, cznr, sigmu, corr_w, czar, &rr_, &s1_, &s2_, nullptr, nullptr);
                     rs.tl += alpha * rd.dtl; rs.ll += alpha * rd.dll;
                     rs.tu += alpha * rd.dtu; rs.lu += alpha * rd.dlu;
-                    reinterpret_cast<dbl2*>(w + Ly.oR1)[hr] = dbl2{rs.tl, rs.tu};
-                    reinterpret_cast<dbl2*>(w + Ly.oR2)[hr] = dbl2{rs.ll, rs.lu};
+                    stnt_b1(dbl2{rs.tl, rs.tu}, reinterpret_cast<dbl2*>(w + Ly.oR1) + hr);
+                    stnt_b1(dbl2{rs.ll, rs.lu}, reinterpret_cast<dbl2*>(w + Ly.oR2) + hr);
                     double Dr;
                     sE[hr] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
                     sD[hr] = Dr;
                     mu_new += row_live ? qp_row_comp(rs, soft, wsoft) : 0.0;
                 }
                 zc += alpha * (znc - zc);
-                w[Ly.oZ + hz] = zc;
+                stnt_s(zc, w + Ly.oZ + hz);
                 lds_fence();
                 QPT(0);
                 load_b1(k > 0 ? k - 1 : 0);
@@ -744,7 +772,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         for (int jx = 0; jx < NX; jx++) a = fma(Pc[hl_x * NX + jx], sB[jx], a);
                     }
                     sPB[hl_x] = a;
-                    w[Ly.oPB + hl_x] = a;
+                    stnt_s(a, w + Ly.oPB + hl_x);
                 }
                 // (fixed trip counts with clamped indices instead of data-dependent loop bounds: the passes of one loop are
                 //  independent, and only a fully unrolled loop lets the scheduler overlap their LDS round trips)
@@ -823,7 +851,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         if (ix < NQ)
                             for (int r = 0; r < MR; r++) gh = fma(sGT[ix * MRP + r], sE[rC0 + r], gh);
                     }
-                    w[Ly.oGH0 + hz] = gh;   // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one
+                    stnt_s(gh, w + Ly.oGH0 + hz);   // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one
                     if (last) {
                         if (hz >= NU) pvn[hz - NU] = gh;
                     } else if (hl < NU) {
@@ -857,7 +885,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             if (NQP > NQ) sWT[hc * NQP + NQ] = 0.0;   // (the other sweeps stage their blocks over this buffer)
                         }
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) w[Ly.oW + i * KS + hc] = col[i];
+                        for (int i = 0; i < NQ; i++) stnt_b1(col[i], w + Ly.oW + i * KS + hc);
                     }
                     lds_fence();
                     QPT(3);
@@ -952,7 +980,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             auto load_w = [&](int k) {
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(k) + Ly.oW);
 #pragma unroll
-                for (int j = 0; j < WST_PF; j++) Ws[j] = s2[min(hl + 32 * j, W_N2 - 1)];
+                for (int j = 0; j < WST_PF; j++) Ws[j] = ldnt(s2 + min(hl + 32 * j, W_N2 - 1));
             };
             auto commit_w = [&](double* dst) {
                 dbl2* d2 = reinterpret_cast<dbl2*>(dst);
@@ -963,15 +991,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 const double* w = stage_ptr(k);
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oC);
 #pragma unroll
-                for (int j = 0; j < CST_PF; j++) Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
+                for (int j = 0; j < CST_PF; j++) Cs[j] = ldnt(s2 + min(hl + 32 * j, c_n2 - 1));
             };
             auto load_r = [&](int k) {
                 const double* w = stage_ptr(k);
-                r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr];
-                r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr];
-                r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
-                if (CORR) r3 = reinterpret_cast<const dbl2*>(w + Ly.oR3)[hr];
-                const dbl2 aux = reinterpret_cast<const dbl2*>(w + Ly.oAUX)[hl_x];
+                r0 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR0) + hr);
+                r1 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR1) + hr);
+                r2 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR2) + hr);
+                if (CORR) r3 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR3) + hr);
+                const dbl2 aux = ldnt_s(reinterpret_cast<const dbl2*>(w + Ly.oAUX) + hl_x);
                 bi = aux.x;
                 wsoft = aux.y;
             };
@@ -1042,7 +1070,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     if (!CORR) {
                         double e1, e2;
                         qp_row_dir<true>(rs, soft, wsoft, cz, 0.0, 0.0, cz, &rr, &s1_, &s2_, &e1, &e2);
-                        w[Ly.oR3 + 2 * hr] = cz;
+                        stnt_s(cz, w + Ly.oR3 + 2 * hr);
                         sD[hr] = e1;     // (B1's D / E arrays are free during the forward sweeps)
                         sE[hr] = e2;
                     } else {
@@ -1050,8 +1078,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         //  load is in flight, which costs a full vmcnt(0) at that point)
                         const double cza = fma(0.0, r3.y, r3.x);
                         qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, cza, &rr, &s1_, &s2_, nullptr, nullptr);
-                        w[Ly.oR3 + 2 * hr + 1] = cz;
-                        w[Ly.oZN + hz] = hz < NU ? sZU[hl_u] : xb[hl_px];
+                        stnt_s(cz, w + Ly.oR3 + 2 * hr + 1);
+                        stnt_s(hz < NU ? sZU[hl_u] : xb[hl_px], w + Ly.oZN + hz);
                     }
                     S1 += row_live ? s1_ : 0.0;
                     S2 += row_live ? s2_ : 0.0;
@@ -1071,8 +1099,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             a2 = fma(c, sE[NX + r], a2);
                         }
                     if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
-                    w[Ly.oA1 + hz] = a1;
-                    w[Ly.oA2 + hz] = a2;
+                    stnt_s(a1, w + Ly.oA1 + hz);
+                    stnt_s(a2, w + Ly.oA2 + hz);
                     lds_fence();   // (the next stage overwrites the staged rows)
                 }
                 { const int t = o_xb; o_xb = o_xn; o_xn = t; }
@@ -1105,15 +1133,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
             auto load_b = [&](BSet& S, int k) {
                 const double* w = stage_ptr(k);
-                S.gh0 = w[Ly.oGH0 + hz];
-                S.a1 = w[Ly.oA1 + hz];
-                S.a2 = w[Ly.oA2 + hz];
-                S.pb1 = w[Ly.oPB + ip1];
-                S.pb2 = w[Ly.oPB + ip2];
+                S.gh0 = ldnt_s(w + Ly.oGH0 + hz);
+                S.a1 = ldnt_s(w + Ly.oA1 + hz);
+                S.a2 = ldnt_s(w + Ly.oA2 + hz);
+                S.pb1 = ldnt_s(w + Ly.oPB + ip1);
+                S.pb2 = ldnt_s(w + Ly.oPB + ip2);
                 const int kf = k < N ? k : N - 1;   // (there are no factors at the end stage)
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(kf) + Ly.oW);
 #pragma unroll
-                for (int j = 0; j < WST_PF; j++) S.Ws[j] = s2[min(hl + 32 * j, W_N2 - 1)];
+                for (int j = 0; j < WST_PF; j++) S.Ws[j] = ldnt(s2 + min(hl + 32 * j, W_N2 - 1));
             };
             auto stage_b2 = [&](BSet& S, int k, auto last_tag) {
                 constexpr bool last = decltype(last_tag)::value;
@@ -1146,7 +1174,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                         for (int j = 0; j < NQ; j++) v = fma(sWstA[hl_u * KS + LC0 + j], sRho[j], v);
                         if (hl < NQ) sWv[hl] = v;
-                        w[Ly.oW + hl_u * KS + NX] = v;   // the corrector's w (F2 reads it with the block)
+                        stnt_s(v, w + Ly.oW + hl_u * KS + NX);   // the corrector's w (F2 reads it with the block)
                     }
                     lds_fence();
                     if (k > 0 && hz >= NU) {
@@ -1209,8 +1237,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         for (int j = 0; j < EP_CH; j++) {
             const int k = k0 + j <= N ? k0 + j : N;
             const double* w = ws + (size_t)k * Ly.stride;
-            zz[j] = w[Ly.oZ + hz];
-            zzn[j] = w[Ly.oZN + hz];
+            zz[j] = ldnt_s(w + Ly.oZ + hz);
+            zzn[j] = ldnt_s(w + Ly.oZN + hz);
             const int ku = k < N ? k : N - 1;
             bb[j] = hl < NU ? ub0[(size_t)ku * NU + hl_u] : xb0[(size_t)k * NX + hl_px];
         }
