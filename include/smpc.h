@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 2
+#define SMPC_ABI_VERSION 3
 
 #define SMPC_MAX_NQ 7
 #define SMPC_MAX_NX 14
@@ -250,6 +250,81 @@ int smpc_plant_step(smpc_handle* h, int B, const double* x, const double* u, con
 int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, double* x_guess, double* u_guess,
                        const double* p, const smpc_joint* joints_noisy, const double* tau_noise, double* x_traj,
                        double* u_traj, int32_t* status_traj, int32_t* iter_traj, int on_device);
+
+/* ---- the policy layer with all state in HBM ------------------------------------------------- */
+/* The reference walks its instances one at a time through <Controller>.step (controller.py:274-284, 375-388, 448-498,
+ * 524-565, 651-661) and the safe-abort loop of scripts/mpc.py:125-264.  These three entry points are those two pieces of code
+ * for B instances at once, state resident on the device, enqueue-only on the handle's stream (no host synchronisation, so a
+ * caller can capture a whole closed-loop step in a hipGraph).  All pointers inside the structs and all array arguments are
+ * DEVICE pointers unless stated otherwise; flags are one byte per instance (0 / 1). */
+enum {
+    SMPC_POLICY_NAIVE = 0,          /* NaiveController / TerminalZeroVelocity / STController                      :274-284 */
+    SMPC_POLICY_STATE_CHECK = 1,    /* ControllerSafeSetEverywhere: success also needs checkStateConstraints       :651-661 */
+    SMPC_POLICY_STWA = 2,           /* STWAController / HTWAController: viable state, abort after N - 1 failures   :375-388 */
+    SMPC_POLICY_RECEDING = 3,       /* RecedingController: receding index r, row switched on at node r             :448-498 */
+    SMPC_POLICY_REAL_RECEDING = 4   /* RealReceding: node r boxed to the planned state +- tube                     :524-565 */
+};
+
+typedef struct {
+    int32_t kind;                   /* SMPC_POLICY_* */
+    int32_t abort_flag;             /* params.abort_flag (controller.py:471-478) */
+    int32_t collision_first_node;   /* != 0: trajectories are collision-tested at their first node only, as the reference's
+                                       checkCollision does (env_model.py:238-243); 0: at every node */
+    int32_t reserved0;
+    double tol_x, alpha, tol_safe;  /* checkStateConstraints / checkSafeConstraints tolerances (env_model.py:170, safe_set.py:61) */
+    double tube;                    /* RealReceding: half-width of the box at node r (1e-3, controller.py:531-532) */
+    const double *x_min, *x_max;            /* HOST [nx]: model bounds of the state test */
+    const double *row_lb_chk, *row_ub_chk;  /* HOST [n_rows]: check bounds of the collision rows */
+    const double *stage_lo, *stage_hi;      /* DEVICE [N+1][nx]: RealReceding's bounds away from node r (NULL otherwise) */
+} smpc_policy_params;
+
+typedef struct {                    /* what a controller object holds per instance (controller.py:112-131) */
+    double *x_guess, *u_guess;      /* [B][N+1][nx], [B][N][nu] */
+    double *x_temp, *u_temp;        /* the iterate of the last solve */
+    double *p;                      /* [B][N+1][5] */
+    double *x_viable;               /* [B][nx] */
+    int64_t *fails, *current_step;  /* [B] */
+    int64_t *r;                     /* [B] receding index (NULL for the policies without one) */
+    int32_t *status, *qp_iter;      /* [B] of the last solve */
+} smpc_policy_state;
+
+/* <Controller>.step(x) for the instances with stepping[b] != 0 (NULL: all): guessCorrection, the policy's flags / bounds,
+ * the RTI solve, the acceptance tests, the fails / r / viable-state automaton, provideControl.  Instances that do not step are
+ * left untouched and skipped by the QP kernels.  u_out[b] = the policy's control, u_guess[b][0] for an instance that raises
+ * abort, u_other[b] for one that did not step (u_other may be NULL when stepping is).  abort_out[b] = the step's second return
+ * value; *any_abort (one int32) is set to 1 if any instance aborted, 0 otherwise. */
+int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const smpc_policy_state* st, const double* x,
+                     const uint8_t* stepping, const double* u_other, double* u_out, uint8_t* abort_out, int32_t* any_abort);
+
+typedef struct {                    /* the driver's per-instance state (scripts/mpc.py:102-124) */
+    double* x_cur;                  /* [B][nx] */
+    uint8_t *alive, *sa, *collided; /* [B]: still simulated / following a backup trajectory / failed */
+    int64_t *ja, *last_x, *last_u;  /* [B]: abort clock; last valid row of the state / input logs */
+    double *x_abort, *u_abort;      /* [B][Nb+1][nx], [B][Nb][nu]: backup trajectories */
+    int64_t* step;                  /* [1]: the step counter j */
+    double *x_log, *u_log;          /* step-major logs [n_steps+1][B][nx], [n_steps][B][nu] */
+    int64_t* r_log;                 /* [n_steps][B] receding index used at each step, -1 where none (or NULL) */
+} smpc_loop_state;
+
+/* scripts/mpc.py:130-151 before the controller's step: PD tracking of the backup trajectory / hold / resume for the instances
+ * in safe abort -> u_other[B][nu]; stepping[b] = alive and not in abort; logs r (may be NULL) of the stepping instances. */
+int smpc_loop_pre(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, const int64_t* r, const uint8_t* pending,
+                  double* u_other, uint8_t* stepping);
+
+/* scripts/mpc.py:161-190, second half: the n_c abort events of the previous step, applied once their backup OCPs (solved as a
+ * compact batch, possibly on another handle / stream that the caller has ordered before this call) are known.  rows[n_c] =
+ * instance of each event, status_c[n_c] / x_c[n_c][Nb+1][nx] / u_c[n_c][Nb][nu] = the backup solves.  Solved: the instance
+ * follows its backup trajectory from this step on (u[b] = PD law on its first node, clock 1), flagged viable; failed: lost at
+ * the step of the event.  pending[b] (the flag smpc_loop_pre reads) is cleared.  Between the event and this call an instance
+ * only has to be kept from stepping, which is what lets the backup solve overlap the next step's solve. */
+int smpc_loop_apply_backup(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, int n_c, const int64_t* rows,
+                           const int32_t* status_c, const double* x_c, const double* u_c, uint8_t* viable, double* u,
+                           uint8_t* pending);
+
+/* scripts/mpc.py:240-264 after it: logs u, plant step (smpc_plant_step semantics), state test of the new state
+ * (par: x_min / x_max / tol_x / row check bounds), logs, outcome flags, next current state, j += 1. */
+int smpc_loop_post(smpc_handle* h, int B, const smpc_policy_params* par, const smpc_loop_state* ls, const double* u,
+                   const smpc_joint* joints_noisy, const double* tau_noise);
 
 /* wait for the handle's stream */
 int smpc_sync(smpc_handle* h);

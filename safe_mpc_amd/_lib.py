@@ -17,11 +17,34 @@ LIB_PATH = os.environ.get('SMPC_HIP_LIB') or os.path.join(_CSRC, 'libsmpc_hip.so
 SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error', 'smpc_set_mlp', 'smpc_set_horizon',
            'smpc_set_stage_bounds', 'smpc_set_slack_weights', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',
            'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_rollout_batch', 'smpc_sync', 'smpc_stream',
-           'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing', 'smpc_get_qp_wave_stats']
+           'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing', 'smpc_get_qp_wave_stats', 'smpc_policy_step', 'smpc_loop_pre',
+           'smpc_loop_post', 'smpc_loop_apply_backup']
 
 
 class EngineError(RuntimeError):
     pass
+
+
+_vp = C.c_void_p
+
+
+class PolicyParams(C.Structure):
+    """smpc_policy_params (include/smpc.h)"""
+    _fields_ = [('kind', C.c_int32), ('abort_flag', C.c_int32), ('collision_first_node', C.c_int32), ('reserved0', C.c_int32),
+                ('tol_x', C.c_double), ('alpha', C.c_double), ('tol_safe', C.c_double), ('tube', C.c_double),
+                ('x_min', _vp), ('x_max', _vp), ('row_lb_chk', _vp), ('row_ub_chk', _vp), ('stage_lo', _vp), ('stage_hi', _vp)]
+
+
+class PolicyState(C.Structure):
+    """smpc_policy_state"""
+    _fields_ = [(k, _vp) for k in ('x_guess', 'u_guess', 'x_temp', 'u_temp', 'p', 'x_viable', 'fails', 'current_step', 'r',
+                                   'status', 'qp_iter')]
+
+
+class LoopState(C.Structure):
+    """smpc_loop_state"""
+    _fields_ = [(k, _vp) for k in ('x_cur', 'alive', 'sa', 'collided', 'ja', 'last_x', 'last_u', 'x_abort', 'u_abort', 'step',
+                                   'x_log', 'u_log', 'r_log')]
 
 
 def build(force=False):
@@ -71,5 +94,9 @@ def lib():
     L.smpc_get_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.smpc_get_qp_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.smpc_get_qp_wave_stats.argtypes = [vp, C.POINTER(C.c_double)]
+    L.smpc_policy_step.argtypes = [vp, C.c_int, C.POINTER(PolicyParams), C.POINTER(PolicyState), dp, dp, dp, dp, dp, dp]
+    L.smpc_loop_pre.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LoopState), dp, dp, dp, dp]
+    L.smpc_loop_apply_backup.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LoopState), C.c_int, dp, dp, dp, dp, dp, dp, dp]
+    L.smpc_loop_post.argtypes = [vp, C.c_int, C.POINTER(PolicyParams), C.POINTER(LoopState), dp, dp, dp]
     _lib = L
     return L

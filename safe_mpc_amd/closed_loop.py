@@ -267,12 +267,31 @@ class _Group(InPlaceState):
         self._ever_aborted = False
         self._use_graphs = bool(use_graphs and xp.on_device)
         self._graphs = {}                     # (half, ever_aborted) -> captured graph
+        # device path: both halves of a step are engine kernels (smpc_loop_pre / smpc_policy_step / smpc_loop_post); the numpy
+        # code below is the readable statement of the same automaton and what the host path runs
+        self._fused = bool(xp.on_device and hasattr(ctrl.ocp_solver, 'loop_pre'))
+        if self._fused:
+            self._u_other = xp.zeros((B, nu))
+            self._stepping = xp.full((B,), True, xp.bool_)
+            self.new_abort = ctrl._abort_out          # (the controller's own output buffer: no copy per step)
+            # abort events: the backup OCPs of a step's events are solved on the backup solver's own stream WHILE the next
+            # step's solve runs; until their outcome is applied (smpc_loop_apply_backup) the instances are only kept from stepping
+            self._pending = xp.full((B,), False, xp.bool_)
+            self._inflight = None
+            import torch
+            bs = backup.ocp_solver
+            self._side = torch.cuda.ExternalStream(bs.L.smpc_stream(bs.h), device=torch.device('cuda', bs.device))
         self._inplace = xp.on_device
 
     # ---- first half: everything up to the controller's verdict ---------------------------------------------------------------
     def part_a(self):
         xp, ctrl, B, Nb = self._xp, self._ctrl, self._B, self._Nb
         nq = ctrl.nq
+        if self._fused:
+            sv = ctrl.ocp_solver
+            sv.loop_pre(self, getattr(ctrl, 'r', None), self._pending, self._u_other, self._stepping)
+            ctrl.step_on_device(self.x_cur, self._stepping, self._u_other, u_out=self.u)
+            return
         kp, kd = 1.0, 1e2                                                               # mpc.py:97
         x_cur = self.x_cur
         if self._ever_aborted:
@@ -310,7 +329,11 @@ class _Group(InPlaceState):
     # ---- the step's host decision: abort events (mpc.py:161-190) -----------------------------------------------------------------
     def handle_aborts(self):
         xp, ctrl, backup, B, Nb = self._xp, self._ctrl, self._backup, self._B, self._Nb
-        if not (ctrl.can_abort and xp.any(self.new_abort)):                         # (the step's one host synchronisation)
+        if not ctrl.can_abort:
+            return
+        if self._fused:
+            return self._handle_aborts_fused()
+        if not xp.any(self.new_abort):                                               # (the step's one host synchronisation)
             return
         self._ever_aborted = True
         # the backup OCP is solved for the aborting instances only (a compact batch), from their viable states
@@ -342,10 +365,51 @@ class _Group(InPlaceState):
         self.sa = self.sa | okb
         self.viable = self.viable | okb
 
+    def _apply_inflight(self):
+        if self._inflight is None:
+            return
+        import torch
+        rows_b, xv_c, xo_c, uo_c, st_c, ev = self._inflight
+        torch.cuda.current_stream().wait_event(ev)
+        self._ctrl.ocp_solver.loop_apply_backup(self, rows_b, st_c, xo_c, uo_c, self.viable, self.u, self._pending)
+        self._inflight = None
+
+    def _handle_aborts_fused(self):
+        """Device path of :meth:`handle_aborts`.  Same events, same outcomes; what differs is WHEN the backup OCP's result is
+        consumed: the solve is enqueued on the backup solver's stream and its outcome applied one step later, after the next
+        controller step has been enqueued -- in between the instance only must not step (``_pending``), which is all the
+        reference's loop needs of it (it either follows the backup trajectory from the next step on or is lost at this one)."""
+        import torch
+        xp, ctrl, backup, Nb = self._xp, self._ctrl, self._backup, self._Nb
+        self._apply_inflight()                               # the previous step's events (their first tracking control goes into u)
+        if not bool(ctrl._any_abort.item()):                 # (the step's one host synchronisation)
+            return
+        self._ever_aborted = True
+        rows = np.where(xp.host(self.new_abort))[0]
+        j = int(xp.host(self._jt)[0])
+        rows_b = xp.asarray(rows, xp.i64)
+        xv_c = ctrl.x_viable[rows_b]
+        n_c = len(rows)
+        self._abort_events.append((rows + self._first, np.full(n_c, j), xp.host(xv_c)))
+        self._pending.copy_(self.new_abort)
+        main = torch.cuda.current_stream()
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev0)
+            xg_c = xp.repeat_nodes(xv_c, Nb + 1)
+            xo_c, uo_c, st_c, _ = backup.ocp_solver.solve(xv_c, xg_c, xp.zeros((n_c, Nb, ctrl.nu)), backup.p[:n_c])
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._inflight = (rows_b, xv_c, xo_c, uo_c, st_c, ev)
+
     # ---- second half: plant, outcome tests, logs ----------------------------------------------------------------------------------
     def part_b(self):
         xp, ctrl, B = self._xp, self._ctrl, self._B
         solver = ctrl.ocp_solver
+        if self._fused:
+            solver.loop_post(self, self.u, self._joints_noisy, self._tau_noise)
+            return
         # plant (mpc.py:240, env_model.py:192-206).  Logs are written unmasked; rows of an instance after its failure are
         # blanked at the end from the step it died at (mpc.py:114 pre-fills them with NaN)
         xp.put_row(self.u_log, self._jt, self.u)
@@ -395,6 +459,8 @@ class _Group(InPlaceState):
                       f'in abort {int(xp.host(self.sa & self.alive).sum())}, failures {int(xp.host(self.collided).sum())}')
             if not xp.on_device and not self.alive.any():
                 break
+        if self._fused:
+            self._apply_inflight()            # (events of the last step)
 
     def results(self):
         xp, ctrl, params, B, n_steps = self._xp, self._ctrl, self._params, self._B, self._n_steps

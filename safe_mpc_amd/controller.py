@@ -25,6 +25,7 @@ class AbstractController(InPlaceState):
     kernels only -- no array crosses PCIe and nothing synchronises with the host.  The default (numpy) is the host path."""
     cont_name = 'naive'
     can_abort = False            # policies whose step() may return abort=True (the driver then needs one flag per step)
+    policy_kind = 0              # SMPC_POLICY_* of include/smpc.h: which automaton smpc_policy_step runs for this class
 
     def __init__(self, params, batch, cost='ext', N=None, solver=None, net=None, device=0, device_state=False):
         self.params = params
@@ -66,6 +67,10 @@ class AbstractController(InPlaceState):
         self.last_status = xp.full((B,), 4, xp.i32)                # controller.py:125
         self.qp_iter = xp.zeros((B,), xp.i32)
         self.x_viable = xp.zeros((B, self.nx))
+        if xp.on_device:       # outputs of the fused device step (smpc_policy_step): fixed addresses, so a step can be graph-captured
+            self._u_out = xp.zeros((B, self.nu))
+            self._abort_out = xp.full((B,), False, xp.bool_)
+            self._any_abort = xp.zeros((1,), xp.i32)
 
     def reset_controller(self):
         self.fails = self.xp.zeros((self.B,), self.xp.i64)
@@ -200,12 +205,20 @@ class AbstractController(InPlaceState):
     def step(self, x):
         raise NotImplementedError
 
+    def step_on_device(self, x, stepping=None, u_other=None, u_out=None):
+        """``step`` with the state in HBM: the class's automaton as engine kernels (smpc_policy_step, kernels_policy.hpp) -- the
+        numpy ``step`` of each class is the readable statement of the same thing, and the GPU tests run the two side by side.
+        ``stepping`` masks out instances that must not step (they are left untouched and get ``u_other``)."""
+        return self.ocp_solver.policy_step(self, x, stepping, u_other, u_out)
+
 
 class NaiveController(AbstractController):
     cont_name = 'naive'
 
     def step(self, x):
         """controller.py:274-284"""
+        if self.xp.on_device:
+            return self.step_on_device(x)
         self.guessCorrection()
         status = self.solve(x)
         self.fails = (self.fails + 1) * self.xp.cast(status != 0, self.xp.i64)      # 0 on success, fails + 1 otherwise
@@ -224,6 +237,7 @@ class STController(NaiveController):
 class STWAController(STController):
     cont_name = 'stwa'
     can_abort = True
+    policy_kind = 2
 
     def setGuess(self, x_guess, u_guess):
         super().setGuess(x_guess, u_guess)
@@ -234,6 +248,8 @@ class STWAController(STController):
 
     def step(self, x):
         """controller.py:375-388"""
+        if self.xp.on_device:
+            return self.step_on_device(x)
         xp = self.xp
         self.guessCorrection()
         status = self.solve(x)
@@ -256,6 +272,7 @@ class HTWAController(STWAController):
 
 class RecedingController(STWAController):
     cont_name = 'receding'
+    policy_kind = 3
 
     def reset_controller(self):
         super().reset_controller()
@@ -299,6 +316,8 @@ class RecedingController(STWAController):
 
     def step(self, x):
         """controller.py:448-498"""
+        if self.xp.on_device:
+            return self.step_on_device(x)
         self.guessCorrection()
         self._set_flags()
         u_abort = self.xp.copy(self.u_guess[:, 0])
@@ -310,9 +329,19 @@ class RealReceding(RecedingController):
     """controller.py:504-565: hard terminal safe set; instead of a running safe-set row, node r of each instance is boxed to
     the previously planned state x_guess[r+1] +- 1e-3 (per-instance stage bounds in the engine).  No guessCorrection."""
     cont_name = 'real_receding'
+    policy_kind = 4
     TUBE = 1e-3
 
+    def _alloc(self):
+        super()._alloc()
+        if self.xp.on_device:      # the bounds away from node r (:534-536): model bounds, the terminal node its own
+            xp = self.xp
+            self._stage_lo = xp.asarray(np.vstack([np.tile(self.problem.x_min, (self.N, 1)), self.problem.lbx_e[None, :]]), xp.f64)
+            self._stage_hi = xp.asarray(np.vstack([np.tile(self.problem.x_max, (self.N, 1)), self.problem.ubx_e[None, :]]), xp.f64)
+
     def step(self, x):
+        if self.xp.on_device:
+            return self.step_on_device(x)
         xp, pr, N = self.xp, self.problem, self.N
         # other nodes: the model bounds (:534-536); the terminal node keeps lbx_e / ubx_e
         k = xp.arange(N + 1)[None, :, None]
@@ -334,9 +363,12 @@ class RealReceding(RecedingController):
 
 class ControllerSafeSetEverywhere(STController):
     cont_name = 'constraint_everywhere'
+    policy_kind = 1
 
     def step(self, x):
         """controller.py:651-661"""
+        if self.xp.on_device:
+            return self.step_on_device(x)
         xp = self.xp
         self.guessCorrection()
         status = self.solve(x)

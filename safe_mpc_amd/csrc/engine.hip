@@ -11,6 +11,7 @@
 #include "../../include/smpc.h"
 #include "kernel_qp.hpp"
 #include "kernels_callers.hpp"
+#include "kernels_policy.hpp"
 #include "kernels_mlp.hpp"
 #include "kernels_nodes.hpp"
 
@@ -70,6 +71,9 @@ struct smpc_handle {
     bool borrowed_mlp = false;            // (a worker: the weight buffers belong to its parent)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* d_wstat = nullptr;   // [4] load-balance probe of k_qp_ipm (timing builds of a call only)
+    const uint8_t* d_active = nullptr;   // smpc_policy_step only: instances the QP kernels skip (borrowed for the call)
+    int32_t* d_polw = nullptr;  // scratch of the policy entry points: verdicts, masks, the next state of the plant
+    size_t polw_bytes = 0;
     int32_t* d_pol = nullptr;   // fails / accept counters of smpc_rollout_batch, [2][pol_B]
     int pol_B = 0;
     float last_ms[4] = {0, 0, 0, 0};
@@ -296,10 +300,10 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
 #define SMPC_QP_LAUNCH(MR_)                                                                                                        \
     do {                                                                                                                           \
         hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
-                           bhi, h->d_zl, h->d_ev, h->d_ws, bstride);                                                               \
+                           bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                                  \
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                           \
         hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
-                           ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat);                                               \
+                           ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active);                                  \
     } while (0)
     switch (h->desc.n_rows) {
     case 6: SMPC_QP_LAUNCH(6); break;
@@ -321,6 +325,72 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     default: rc = fail(h, SMPC_EINVAL, "nq=%d not built (5, 6, 7)", (h)->desc.nq); \
     }
 
+
+// The check bounds of the state tests live in a small device block of their own and are uploaded only when they change: a
+// copy from pageable host memory waits for the stream to drain, which would turn every per-step call of a device-resident
+// loop into a host synchronisation.
+int upload_check_bounds(smpc_handle* h, const double* x_min, const double* x_max, const double* row_lb_chk,
+                        const double* row_ub_chk) {
+    const int nx = 2 * h->desc.nq, nr = h->desc.n_rows;
+    std::vector<double> cur((size_t)2 * nx + 2 * SMPC_MAX_ROWS, 0.0);
+    memcpy(cur.data(), x_min, sizeof(double) * nx);
+    memcpy(cur.data() + nx, x_max, sizeof(double) * nx);
+    if (nr > 0) {
+        memcpy(cur.data() + 2 * nx, row_lb_chk, sizeof(double) * nr);
+        memcpy(cur.data() + 2 * nx + SMPC_MAX_ROWS, row_ub_chk, sizeof(double) * nr);
+    }
+    if (!h->d_chk) HIPCHK(h, hipMalloc((void**)&h->d_chk, cur.size() * sizeof(double)));
+    if (cur != h->chk_cache) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(h->d_chk, cur.data(), cur.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->chk_cache.swap(cur);
+    }
+    return SMPC_OK;
+}
+
+// state test (+ safe-set test if d_nn) of B trajectories of n_nodes nodes on the device, against the uploaded check bounds;
+// collision rows on the leading coll_nodes nodes only
+int check_nodes_dev(smpc_handle* h, int B, int n_nodes, const double* d_x, double tol_x, int coll_nodes, double alpha,
+                    double tol_safe, int32_t* d_ok, int32_t* d_nn) {
+    const int nq = h->desc.nq, nx = 2 * nq;
+    hipStream_t s = h->stream;
+    const size_t M = (size_t)B * n_nodes;
+    double* d_min = h->d_chk;
+    double* d_max = d_min + nx;
+    double* d_rlb = d_max + nx;
+    double* d_rub = d_rlb + SMPC_MAX_ROWS;
+    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)d_ok, 1, (size_t)B, s));   // verdicts start at "ok", stream-ordered
+    const dim3 grd((unsigned)((M + 127) / 128)), blk(128);
+    switch (nq) {
+    case 5: hipLaunchKernelGGL((k_check_nodes<5>), grd, blk, 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok, coll_nodes); break;
+    case 6: hipLaunchKernelGGL((k_check_nodes<6>), grd, blk, 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok, coll_nodes); break;
+    default: hipLaunchKernelGGL((k_check_nodes<7>), grd, blk, 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok, coll_nodes); break;
+    }
+    HIPCHK(h, hipGetLastError());
+    if (d_nn) {
+        int rc;
+        DISPATCH_NQ(h, (run_mlp<NQ_>(h, (int)M, 0, 0, d_x, false)));
+        if (rc) return rc;
+        const dim3 g2((unsigned)((M + 255) / 256)), b2(256);
+        switch (nq) {
+        case 5: hipLaunchKernelGGL((k_check_nn<5>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
+        case 6: hipLaunchKernelGGL((k_check_nn<6>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
+        default: hipLaunchKernelGGL((k_check_nn<7>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
+        }
+        HIPCHK(h, hipGetLastError());
+    }
+    return SMPC_OK;
+}
+
+// scratch of the policy entry points (grown on demand: the first, eager steps of a loop; never inside a graph capture)
+int ensure_polw(smpc_handle* h, size_t bytes) {
+    if (bytes <= h->polw_bytes) return SMPC_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_polw) { (void)hipFree(h->d_polw); h->d_polw = nullptr; h->polw_bytes = 0; }
+    if (hipMalloc((void**)&h->d_polw, bytes) != hipSuccess) return fail(h, SMPC_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    h->polw_bytes = bytes;
+    return SMPC_OK;
+}
 
 // Worker handles of smpc_rollout_batch: same problem, own stream and workspaces, the parent's network weights (borrowed).
 int rollout_workers(smpc_handle* h, int n) {
@@ -432,6 +502,7 @@ void smpc_destroy(smpc_handle* h) {
     }
     for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
     if (h->d_pol) (void)hipFree(h->d_pol);
+    if (h->d_polw) (void)hipFree(h->d_polw);
     if (h->d_roll) (void)hipFree(h->d_roll);
     if (h->d_chk) (void)hipFree(h->d_chk);
     if (h->d_wstat) (void)hipFree(h->d_wstat);
@@ -607,7 +678,7 @@ int smpc_guess_correction(smpc_handle* h, int B, double* xg, const double* ug, i
         HIPCHK(h, hipMemcpyAsync(duw, ug, sizeof(double) * B * N * nq, hipMemcpyHostToDevice, s));
         du = duw;
     }
-    hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 255) / 256), dim3(256), 0, s, B, N, nq, h->desc.dt, dx, du);
+    hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 255) / 256), dim3(256), 0, s, B, N, nq, h->desc.dt, dx, du, (const uint8_t*)nullptr);
     HIPCHK(h, hipGetLastError());
     if (!on_device) {
         HIPCHK(h, hipMemcpyAsync(xg, dx, sizeof(double) * B * (N + 1) * nx, hipMemcpyDeviceToHost, s));
@@ -626,7 +697,7 @@ int smpc_provide_control(smpc_handle* h, int B, const int32_t* accept, const dou
     const size_t nX = (size_t)B * (N + 1) * nx, nU = (size_t)B * N * nq;
     if (on_device) {
         hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, accept, x_temp,
-                           u_temp, xg, ug, u_apply);
+                           u_temp, xg, ug, u_apply, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const double*)nullptr);
         HIPCHK(h, hipGetLastError());
         return SMPC_OK;
     }
@@ -644,7 +715,7 @@ int smpc_provide_control(smpc_handle* h, int B, const int32_t* accept, const dou
     HIPCHK(h, hipMemcpyAsync(d_ug, ug, sizeof(double) * nU, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_acc, accept, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, d_acc, d_xt, d_ut,
-                       d_xg, d_ug, d_ua);
+                       d_xg, d_ug, d_ua, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const double*)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(xg, d_xg, sizeof(double) * nX, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(ug, d_ug, sizeof(double) * nU, hipMemcpyDeviceToHost, s));
@@ -661,35 +732,14 @@ int smpc_check_trajectory(smpc_handle* h, int B, int n_nodes, const double* x, c
     if (h->desc.n_rows > 0 && (!row_lb_chk || !row_ub_chk)) return fail(h, SMPC_EINVAL, "row check bounds missing");
     if (nn_ok && h->nlayers == 0) return fail(h, SMPC_ESTATE, "nn_ok requested but smpc_set_mlp was not called");
     (void)hipSetDevice(h->device);
-    const int nq = h->desc.nq, nx = 2 * nq, nr = h->desc.n_rows;
+    const int nq = h->desc.nq, nx = 2 * nq;
     hipStream_t s = h->stream;
     const size_t M = (size_t)B * n_nodes;
     // (x_min / x_max / row bounds are host pointers on both paths: small, constant per caller)
     int rc;
     const size_t big = on_device ? 0 : sizeof(double) * M * nx + sizeof(int32_t) * (B + M) + 64;
     if ((rc = ensure_tmp(h, big))) return rc;
-    // The check bounds live in a small device block of their own and are uploaded only when they change: a copy from
-    // pageable host memory waits for the stream to drain, which would turn every per-step call of a device-resident loop
-    // into a host synchronisation.
-    {
-        std::vector<double> cur((size_t)2 * nx + 2 * SMPC_MAX_ROWS, 0.0);
-        memcpy(cur.data(), x_min, sizeof(double) * nx);
-        memcpy(cur.data() + nx, x_max, sizeof(double) * nx);
-        if (nr > 0) {
-            memcpy(cur.data() + 2 * nx, row_lb_chk, sizeof(double) * nr);
-            memcpy(cur.data() + 2 * nx + SMPC_MAX_ROWS, row_ub_chk, sizeof(double) * nr);
-        }
-        if (!h->d_chk) HIPCHK(h, hipMalloc((void**)&h->d_chk, cur.size() * sizeof(double)));
-        if (cur != h->chk_cache) {
-            HIPCHK(h, hipStreamSynchronize(s));
-            HIPCHK(h, hipMemcpy(h->d_chk, cur.data(), cur.size() * sizeof(double), hipMemcpyHostToDevice));
-            h->chk_cache.swap(cur);
-        }
-    }
-    double* d_min = h->d_chk;
-    double* d_max = d_min + nx;
-    double* d_rlb = d_max + nx;
-    double* d_rub = d_rlb + SMPC_MAX_ROWS;
+    if ((rc = upload_check_bounds(h, x_min, x_max, row_lb_chk, row_ub_chk))) return rc;
     const double* d_x = x;
     int32_t *d_ok = state_ok, *d_nn = nn_ok;
     if (!on_device) {
@@ -699,23 +749,7 @@ int smpc_check_trajectory(smpc_handle* h, int B, int n_nodes, const double* x, c
         d_ok = (int32_t*)(dx + M * nx);
         d_nn = d_ok + B;
     }
-    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)d_ok, 1, (size_t)B, s));   // verdicts start at "ok", stream-ordered
-    switch (nq) {
-    case 5: hipLaunchKernelGGL((k_check_nodes<5>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
-    case 6: hipLaunchKernelGGL((k_check_nodes<6>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
-    default: hipLaunchKernelGGL((k_check_nodes<7>), dim3((unsigned)((M + 127) / 128)), dim3(128), 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok); break;
-    }
-    HIPCHK(h, hipGetLastError());
-    if (nn_ok) {
-        DISPATCH_NQ(h, (run_mlp<NQ_>(h, (int)M, 0, 0, d_x, false)));
-        if (rc) return rc;
-        switch (nq) {
-        case 5: hipLaunchKernelGGL((k_check_nn<5>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
-        case 6: hipLaunchKernelGGL((k_check_nn<6>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
-        default: hipLaunchKernelGGL((k_check_nn<7>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
-        }
-        HIPCHK(h, hipGetLastError());
-    }
+    if ((rc = check_nodes_dev(h, B, n_nodes, d_x, tol_x, n_nodes, alpha, tol_safe, d_ok, nn_ok ? d_nn : nullptr))) return rc;
     if (!on_device) {
         HIPCHK(h, hipMemcpyAsync(state_ok, d_ok, sizeof(int32_t) * B, hipMemcpyDeviceToHost, s));
         if (nn_ok) HIPCHK(h, hipMemcpyAsync(nn_ok, d_nn, sizeof(int32_t) * M, hipMemcpyDeviceToHost, s));
@@ -901,6 +935,136 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
         if (hipStreamSynchronize(s) != hipSuccess && rc == SMPC_OK) rc = fail(h, SMPC_EHIP, "stream synchronisation failed");
     }
     return rc;
+}
+
+// ---- the policy layer on the device ------------------------------------------------------------------------------------------
+int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const smpc_policy_state* st, const double* x,
+                     const uint8_t* stepping, const double* u_other, double* u_out, uint8_t* abort_out, int32_t* any_abort) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !par || !st || !x || !u_out || !abort_out || !any_abort) return fail(h, SMPC_EINVAL, "bad argument");
+    if (!st->x_guess || !st->u_guess || !st->x_temp || !st->u_temp || !st->p || !st->x_viable || !st->fails ||
+        !st->current_step || !st->status || !st->qp_iter)
+        return fail(h, SMPC_EINVAL, "policy state incomplete");
+    const int kind = par->kind;
+    if (kind < SMPC_POLICY_NAIVE || kind > SMPC_POLICY_REAL_RECEDING) return fail(h, SMPC_EINVAL, "unknown policy kind %d", kind);
+    const bool receding = kind == SMPC_POLICY_RECEDING || kind == SMPC_POLICY_REAL_RECEDING;
+    if (receding && !st->r) return fail(h, SMPC_EINVAL, "receding policy without r");
+    if (kind == SMPC_POLICY_REAL_RECEDING && (!par->stage_lo || !par->stage_hi)) return fail(h, SMPC_EINVAL, "stage_lo / stage_hi missing");
+    if (stepping && !u_other) return fail(h, SMPC_EINVAL, "u_other missing");
+    if (kind != SMPC_POLICY_NAIVE && (!par->x_min || !par->x_max || (h->desc.n_rows > 0 && (!par->row_lb_chk || !par->row_ub_chk))))
+        return fail(h, SMPC_EINVAL, "check bounds missing");
+    if (receding && h->nlayers == 0) return fail(h, SMPC_ESTATE, "receding policy but smpc_set_mlp was not called");
+    (void)hipSetDevice(h->device);
+    const int N = h->N, nq = h->desc.nq, nx = 2 * nq;
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = ensure_batch(h, B))) return rc;
+    // scratch: state_ok [B] | safe [B][N+1] | accept [B] | active [B] bytes
+    const size_t nI = (size_t)B * (N + 3);
+    if ((rc = ensure_polw(h, sizeof(int32_t) * nI + (size_t)B + 64))) return rc;
+    int32_t* d_ok = h->d_polw;
+    int32_t* d_safe = d_ok + B;
+    int32_t* d_acc = d_safe + (size_t)B * (N + 1);
+    uint8_t* d_act = (uint8_t*)(d_acc + B);
+    if (kind != SMPC_POLICY_NAIVE && (rc = upload_check_bounds(h, par->x_min, par->x_max, par->row_lb_chk, par->row_ub_chk))) return rc;
+    HIPCHK(h, hipMemsetAsync(any_abort, 0, sizeof(int32_t), s));
+    // guessCorrection (not RealReceding, controller.py:524-565)
+    if (kind != SMPC_POLICY_REAL_RECEDING)
+        hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 255) / 256), dim3(256), 0, s, B, N, nq, h->desc.dt, st->x_guess,
+                           st->u_guess, stepping);
+    if (receding) {
+        if (kind == SMPC_POLICY_REAL_RECEDING) {
+            const size_t n = (size_t)B * (N + 1) * nx;
+            if (n > h->inst_cap) {
+                HIPCHK(h, hipStreamSynchronize(s));
+                if ((rc = dev_alloc(h, &h->d_lo_b, n))) return rc;
+                if ((rc = dev_alloc(h, &h->d_hi_b, n))) return rc;
+                h->inst_cap = n;
+                // (instances that never step keep valid bounds)
+                HIPCHK(h, hipMemsetAsync(h->d_lo_b, 0, n * sizeof(double), s));
+                HIPCHK(h, hipMemsetAsync(h->d_hi_b, 0, n * sizeof(double), s));
+            }
+            h->inst_B = B;
+        }
+        hipLaunchKernelGGL(k_policy_pre, dim3((unsigned)(((size_t)B * (N + 1) + 255) / 256)), dim3(256), 0, s, B, N, nx, kind,
+                           stepping, st->r, st->p, st->x_guess, par->stage_lo, par->stage_hi, par->tube, h->d_lo_b, h->d_hi_b);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->d_active = stepping;
+    DISPATCH_NQ(h, (launch_solve<NQ_>(h, B, x, st->x_guess, st->u_guess, st->p, st->x_temp, st->u_temp, st->status, st->qp_iter)));
+    h->d_active = nullptr;
+    if (rc) return rc;
+    if (kind != SMPC_POLICY_NAIVE) {
+        // checkStateConstraints(x_temp) (+ checkSafeConstraints(x_temp) on every node for the receding policies)
+        const int coll = par->collision_first_node ? 1 : N + 1;
+        if ((rc = check_nodes_dev(h, B, N + 1, st->x_temp, par->tol_x, coll, par->alpha, par->tol_safe, d_ok, receding ? d_safe : nullptr)))
+            return rc;
+    }
+    hipLaunchKernelGGL(k_policy_post, dim3((B + 255) / 256), dim3(256), 0, s, B, N, nx, kind, par->abort_flag, stepping, st->status,
+                       d_ok, d_safe, st->x_guess, st->fails, st->current_step, st->r, st->x_viable, d_acc, d_act, abort_out, any_abort);
+    hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, d_acc, st->x_temp, st->u_temp,
+                       st->x_guess, st->u_guess, u_out, stepping, d_act, u_other);
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
+}
+
+int smpc_loop_pre(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, const int64_t* r, const uint8_t* pending, double* u_other,
+                  uint8_t* stepping) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || Nb <= 0 || !ls || !u_other || !stepping) return fail(h, SMPC_EINVAL, "bad argument");
+    if (!ls->x_cur || !ls->alive || !ls->sa || !ls->ja || !ls->x_abort || !ls->u_abort || !ls->step)
+        return fail(h, SMPC_EINVAL, "loop state incomplete");
+    (void)hipSetDevice(h->device);
+    hipLaunchKernelGGL(k_loop_pre, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->desc.nq, Nb, ls->x_cur, ls->alive, ls->sa,
+                       ls->ja, ls->x_abort, ls->u_abort, r, ls->step, ls->r_log, u_other, stepping, pending);
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
+}
+
+int smpc_loop_apply_backup(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, int n_c, const int64_t* rows,
+                           const int32_t* status_c, const double* x_c, const double* u_c, uint8_t* viable, double* u,
+                           uint8_t* pending) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || Nb <= 0 || n_c < 0 || n_c > B || !ls || !viable || !u || !pending) return fail(h, SMPC_EINVAL, "bad argument");
+    if (n_c == 0) return SMPC_OK;
+    if (!rows || !status_c || !x_c || !u_c) return fail(h, SMPC_EINVAL, "bad argument");
+    if (!ls->x_cur || !ls->alive || !ls->sa || !ls->collided || !ls->ja || !ls->last_x || !ls->last_u || !ls->x_abort ||
+        !ls->u_abort || !ls->step)
+        return fail(h, SMPC_EINVAL, "loop state incomplete");
+    (void)hipSetDevice(h->device);
+    hipLaunchKernelGGL(k_loop_apply_backup, dim3((n_c + 63) / 64), dim3(64), 0, h->stream, n_c, h->desc.nq, Nb, rows, status_c, x_c, u_c,
+                       ls->x_cur, ls->step, ls->alive, ls->sa, ls->collided, viable, ls->ja, ls->last_x, ls->last_u, ls->x_abort,
+                       ls->u_abort, u, pending);
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
+}
+
+int smpc_loop_post(smpc_handle* h, int B, const smpc_policy_params* par, const smpc_loop_state* ls, const double* u,
+                   const smpc_joint* joints_noisy, const double* tau_noise) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !par || !ls || !u) return fail(h, SMPC_EINVAL, "bad argument");
+    if (!ls->x_cur || !ls->alive || !ls->collided || !ls->last_x || !ls->last_u || !ls->step || !ls->x_log || !ls->u_log)
+        return fail(h, SMPC_EINVAL, "loop state incomplete");
+    if (!par->x_min || !par->x_max || (h->desc.n_rows > 0 && (!par->row_lb_chk || !par->row_ub_chk)))
+        return fail(h, SMPC_EINVAL, "check bounds missing");
+    (void)hipSetDevice(h->device);
+    const int nq = h->desc.nq, nx = 2 * nq;
+    hipStream_t s = h->stream;
+    int rc;
+    // scratch behind smpc_policy_step's (same handle, stream-ordered): x_next [B][nx] | ok [B]
+    const size_t off = (sizeof(int32_t) * (size_t)B * (h->N + 3) + (size_t)B + 64 + 15) & ~(size_t)15;
+    if ((rc = ensure_polw(h, off + sizeof(double) * (size_t)B * nx + sizeof(int32_t) * (size_t)B))) return rc;
+    double* d_xn = (double*)((char*)h->d_polw + off);
+    int32_t* d_okn = (int32_t*)(d_xn + (size_t)B * nx);
+    if ((rc = upload_check_bounds(h, par->x_min, par->x_max, par->row_lb_chk, par->row_ub_chk))) return rc;
+    if ((rc = smpc_plant_step(h, B, ls->x_cur, u, joints_noisy, tau_noise, d_xn, nullptr, 1))) return rc;
+    // one node per instance: the model bounds widened by tol_x and the rows against their check bounds = checkStateConstraints
+    if ((rc = check_nodes_dev(h, B, 1, d_xn, par->tol_x, 1, 0.0, 0.0, d_okn, nullptr))) return rc;
+    hipLaunchKernelGGL(k_loop_post, dim3((B + 255) / 256), dim3(256), 0, s, B, nq, u, d_xn, d_okn, ls->step, ls->x_log, ls->u_log,
+                       ls->alive, ls->collided, ls->last_x, ls->last_u, ls->x_cur);
+    hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(1), 0, s, ls->step);
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
 }
 
 int smpc_sync(smpc_handle* h) {

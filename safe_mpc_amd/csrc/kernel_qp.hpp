@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
                                                  const double* __restrict__ ug, const double* __restrict__ pp,
                                                  const double* __restrict__ lo_st, const double* __restrict__ hi_st,
                                                  const double* __restrict__ zl_st, const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
-                                                 long bnd_stride) {
+                                                 long bnd_stride, const uint8_t* __restrict__ active) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, NL = 32;
     constexpr int MAXRC = NQ + (MRT >= 0 ? MRT : SMPC_MAX_ROWS) + 1;
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
     const long pi = 2L * blockIdx.x + half;
     if (pi >= (long)B * (N + 1)) return;
     const int b = (int)(pi / (N + 1)), k = (int)(pi - (long)b * (N + 1));
+    if (active && !active[b]) return;   // (policy layer: this instance does not step its controller; k_qp_ipm skips it too)
     const LyT Ly(MRT >= 0 ? MRT : D->n_rows);
     const int MR = Ly.MR, MRP = Ly.MRP, NRC = Ly.NRC, NRT = Ly.NRT;
     const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const smpc_problem_desc* __restrict__ D, int B, int N, const double* __restrict__ x0, const double* __restrict__ xg,
     const double* __restrict__ ug, double* __restrict__ ws_all, double* __restrict__ x_out, double* __restrict__ u_out,
     int32_t* __restrict__ status, int32_t* __restrict__ qp_iter, const int32_t* __restrict__ order,
-    int32_t* __restrict__ last_iter, unsigned long long* __restrict__ wstat) {
+    int32_t* __restrict__ last_iter, unsigned long long* __restrict__ wstat, const uint8_t* __restrict__ active) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
                   LC0 = LyT::LC0, KS = LyT::KS;
@@ -563,6 +564,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // longest-expected-first dispatch: slot i takes the instance with the i-th largest iteration count of the previous
     // call (instances are independent, so the order only changes the makespan, never a result)
     const int b = order ? order[slot] : slot;
+    if (active && !active[b]) {
+        // the policy layer masks out instances that do not step their controller (dead, or following a backup trajectory):
+        // their state can be anywhere, and an infeasible QP running to its iteration cap would set the launch time
+        if (hl == 0) {
+            status[b] = SMPC_STATUS_SUCCESS;
+            if (qp_iter) qp_iter[b] = 0;
+            if (last_iter) last_iter[b] = 0;
+        }
+        return;
+    }
     const LyT Ly(MRT >= 0 ? MRT : D->n_rows);
     const int MR = Ly.MR, MRP = Ly.MRP, NRC = Ly.NRC, NRT = Ly.NRT;
     const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;

@@ -5,12 +5,14 @@
 
 namespace smpc {
 
-// guessCorrection (controller.py:226-231): one thread per (instance, joint), sequential in k
+// guessCorrection (controller.py:226-231): one thread per (instance, joint), sequential in k.  `mask` (or null): instances
+// with mask[b] == 0 are left alone (the policy layer: instances that do not step their controller this time).
 __global__ void k_guess_correction(int B, int N, int nq, double dt, double* __restrict__ xg,
-                                   const double* __restrict__ ug) {
+                                   const double* __restrict__ ug, const uint8_t* __restrict__ mask) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)B * nq) return;
     const long b = t / nq;
+    if (mask && !mask[b]) return;
     const int i = (int)(t % nq);
     const int nx = 2 * nq;
     double* x = xg + b * (N + 1) * nx;
@@ -26,16 +28,26 @@ __global__ void k_guess_correction(int B, int N, int nq, double dt, double* __re
     }
 }
 
-// provideControl (controller.py:169-184): one thread per (instance, column of x or u)
+// provideControl (controller.py:169-184): one thread per (instance, column of x or u).  The policy layer passes two masks (or
+// null): an instance with stepping[b] == 0 keeps its guess and gets u_other[b] (the driver's PD law); one that stepped but
+// aborted (active[b] == 0) keeps its guess and applies its first row (the early `return self.u_guess[0], True` of
+// controller.py:384-385, 483-487).
 __global__ void k_provide_control(int B, int N, int nq, const int32_t* __restrict__ accept,
                                   const double* __restrict__ xt, const double* __restrict__ ut,
-                                  double* __restrict__ xg, double* __restrict__ ug, double* __restrict__ u_apply) {
+                                  double* __restrict__ xg, double* __restrict__ ug, double* __restrict__ u_apply,
+                                  const uint8_t* __restrict__ stepping, const uint8_t* __restrict__ active,
+                                  const double* __restrict__ u_other) {
     const int nx = 2 * nq, ncol = nx + nq;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)B * ncol) return;
     const long b = t / ncol;
     const int c = (int)(t % ncol);
     const bool acc = accept[b] != 0;
+    const bool stp = !stepping || stepping[b], act = stp && (!active || active[b]);
+    if (!act) {
+        if (c >= nx) u_apply[b * nq + c - nx] = stp ? ug[b * N * nq + c - nx] : u_other[b * nq + c - nx];
+        return;
+    }
     if (c < nx) {
         double* x = xg + b * (N + 1) * nx;
         const double* src = acc ? xt + b * (N + 1) * nx : x;
@@ -58,7 +70,7 @@ template <int NQ>
 __global__ void k_check_nodes(const smpc_problem_desc* __restrict__ D, int B, int n_nodes, const double* __restrict__ x,
                               const double* __restrict__ x_min, const double* __restrict__ x_max, double tol_x,
                               const double* __restrict__ row_lb, const double* __restrict__ row_ub,
-                              int32_t* __restrict__ state_ok) {
+                              int32_t* __restrict__ state_ok, int coll_nodes) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)B * n_nodes) return;
     constexpr int NX = 2 * NQ;
@@ -66,6 +78,12 @@ __global__ void k_check_nodes(const smpc_problem_desc* __restrict__ D, int B, in
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < NX; i++) ok = ok && (xk[i] >= x_min[i] - tol_x) && (xk[i] <= x_max[i] + tol_x);
+    // (the reference's checkCollision returns after the first row of a trajectory, env_model.py:238-243: callers that keep
+    //  that quirk collision-test the leading coll_nodes nodes only)
+    if ((int)(t % n_nodes) >= coll_nodes) {
+        if (!ok) atomicAnd(&state_ok[t / n_nodes], 0);
+        return;
+    }
     double q[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; i++) q[i] = xk[i];

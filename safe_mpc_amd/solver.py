@@ -321,6 +321,61 @@ class BatchedOcpSolver:
                                             xt.ctypes.data, ut.ctypes.data, st.ctypes.data, it.ctypes.data, 0))
         return xt, ut, st, it, xg, ug
 
+    # -- the policy layer with all state in HBM (smpc_policy_step / smpc_loop_pre / smpc_loop_post) -------------------------------
+    def _policy_params(self, kind=0, abort_flag=0, tube=0.0, stage_lo=None, stage_hi=None):
+        """smpc_policy_params from the problem's parameters; the small host arrays it points to are kept alive here"""
+        pr, par = self.problem, self.problem.params
+        small = [np.ascontiguousarray(a, np.float64) for a in (pr.x_min, pr.x_max, pr.row_check[:, 0], pr.row_check[:, 1])]
+        pp = _lib.PolicyParams(int(kind), int(bool(abort_flag)), int(bool(getattr(par, 'reference_quirks', True))), 0,
+                               float(par.tol_x), float(par.alpha), float(par.tol_safe_set), float(tube),
+                               small[0].ctypes.data, small[1].ctypes.data, small[2].ctypes.data, small[3].ctypes.data,
+                               stage_lo.data_ptr() if stage_lo is not None else None,
+                               stage_hi.data_ptr() if stage_hi is not None else None)
+        pp._keep = small
+        return pp
+
+    def policy_step(self, ctrl, x, stepping=None, u_other=None, u_out=None):
+        """<Controller>.step(x) of ``ctrl`` (device state) as engine kernels.  Returns (u, abort) -- persistent tensors of the
+        controller -- and leaves "did any instance abort" in ``ctrl._any_abort`` (one int32 on the device)."""
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        pp = self._policy_params(ctrl.policy_kind, getattr(ctrl, 'abort_flag', False), getattr(ctrl, 'TUBE', 0.0),
+                                 getattr(ctrl, '_stage_lo', None), getattr(ctrl, '_stage_hi', None))
+        st = _lib.PolicyState(ptr(ctrl.x_guess), ptr(ctrl.u_guess), ptr(ctrl.x_temp), ptr(ctrl.u_temp), ptr(ctrl.p), ptr(ctrl.x_viable),
+                              ptr(ctrl.fails), ptr(ctrl.current_step), ptr(getattr(ctrl, 'r', None)), ptr(ctrl.last_status),
+                              ptr(ctrl.qp_iter))
+        u_out = ctrl._u_out if u_out is None else u_out
+        with self._ordered(1):
+            self._chk(self.L.smpc_policy_step(self.h, ctrl.B, C.byref(pp), C.byref(st), x.data_ptr(), ptr(stepping), ptr(u_other),
+                                              u_out.data_ptr(), ctrl._abort_out.data_ptr(), ctrl._any_abort.data_ptr()))
+        return u_out, ctrl._abort_out
+
+    def _loop_state(self, g):
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        return _lib.LoopState(ptr(g.x_cur), ptr(g.alive), ptr(g.sa), ptr(g.collided), ptr(g.ja), ptr(g.last_x), ptr(g.last_u),
+                              ptr(g.x_abort), ptr(g.u_abort), ptr(g._jt), ptr(g.x_log), ptr(g.u_log), ptr(g.r_log))
+
+    def loop_pre(self, g, r, pending, u_other, stepping):
+        """scripts/mpc.py:130-151 for the group ``g`` (closed_loop._Group, device state)"""
+        ls = self._loop_state(g)
+        with self._ordered(1):
+            self._chk(self.L.smpc_loop_pre(self.h, g._B, g._Nb, C.byref(ls), r.data_ptr() if r is not None else None,
+                                           pending.data_ptr() if pending is not None else None, u_other.data_ptr(), stepping.data_ptr()))
+
+    def loop_apply_backup(self, g, rows, status_c, x_c, u_c, viable, u, pending):
+        """scripts/mpc.py:161-190 (second half) for the previous step's abort events, see smpc_loop_apply_backup"""
+        ls = self._loop_state(g)
+        with self._ordered(1):
+            self._chk(self.L.smpc_loop_apply_backup(self.h, g._B, g._Nb, C.byref(ls), int(rows.shape[0]), rows.data_ptr(), status_c.data_ptr(),
+                                                    x_c.data_ptr(), u_c.data_ptr(), viable.data_ptr(), u.data_ptr(), pending.data_ptr()))
+
+    def loop_post(self, g, u, joints_noisy=None, tau_noise=None):
+        """scripts/mpc.py:240-264: plant, outcome tests, logs, j += 1"""
+        ls, pp = self._loop_state(g), self._policy_params()
+        with self._ordered(1):
+            self._chk(self.L.smpc_loop_post(self.h, g._B, C.byref(pp), C.byref(ls), u.data_ptr(),
+                                            joints_noisy.data_ptr() if joints_noisy is not None else None,
+                                            tau_noise.data_ptr() if tau_noise is not None else None))
+
     def plant_step(self, x, u, joints_noisy=None, tau_noise=None):
         """AdamModel.integrate (env_model.py:192-206) for B instances."""
         B = x.shape[0]
