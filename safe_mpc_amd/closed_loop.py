@@ -327,12 +327,12 @@ class _Group(InPlaceState):
         self.new_abort = ab & stepping
 
     # ---- the step's host decision: abort events (mpc.py:161-190) -----------------------------------------------------------------
-    def handle_aborts(self):
+    def handle_aborts(self, j=None):
         xp, ctrl, backup, B, Nb = self._xp, self._ctrl, self._backup, self._B, self._Nb
         if not ctrl.can_abort:
             return
         if self._fused:
-            return self._handle_aborts_fused()
+            return self._handle_aborts_fused(j)
         if not xp.any(self.new_abort):                                               # (the step's one host synchronisation)
             return
         self._ever_aborted = True
@@ -374,7 +374,7 @@ class _Group(InPlaceState):
         self._ctrl.ocp_solver.loop_apply_backup(self, rows_b, st_c, xo_c, uo_c, self.viable, self.u, self._pending)
         self._inflight = None
 
-    def _handle_aborts_fused(self):
+    def _handle_aborts_fused(self, j):
         """Device path of :meth:`handle_aborts`.  Same events, same outcomes; what differs is WHEN the backup OCP's result is
         consumed: the solve is enqueued on the backup solver's stream and its outcome applied one step later, after the next
         controller step has been enqueued -- in between the instance only must not step (``_pending``), which is all the
@@ -386,11 +386,10 @@ class _Group(InPlaceState):
             return
         self._ever_aborted = True
         rows = np.where(xp.host(self.new_abort))[0]
-        j = int(xp.host(self._jt)[0])
         rows_b = xp.asarray(rows, xp.i64)
         xv_c = ctrl.x_viable[rows_b]
         n_c = len(rows)
-        self._abort_events.append((rows + self._first, np.full(n_c, j), xp.host(xv_c)))
+        self._abort_events.append((rows + self._first, np.full(n_c, j), xv_c))      # (xv_c goes to the host in results())
         self._pending.copy_(self.new_abort)
         main = torch.cuda.current_stream()
         ev0 = torch.cuda.Event()
@@ -452,7 +451,7 @@ class _Group(InPlaceState):
         for j in range(self._n_steps):
             self._run_half('a', self.part_a, j)
             yield j
-            self.handle_aborts()
+            self.handle_aborts(j)
             self._run_half('b', self.part_b, j)
             if self._callback and j % 50 == 0:
                 print(f'step {j} (instances {self._first}..{self._first + self._B - 1}): alive {int(xp.host(self.alive).sum())}/{self._B}, '
@@ -478,7 +477,8 @@ class _Group(InPlaceState):
         ee = xp.host(ev['ee'])[:, 0, :]
         conv = xp.host(self.alive) & ~np.isnan(x_sim[:, -1]).any(1) & (np.linalg.norm(ee - pr.ee_ref, axis=1) < params.tol_conv)
         return dict(x=x_sim, u=u_sim, r_receding=np.transpose(xp.host(self.r_log), (1, 0))[:, :, None], conv=conv,
-                    collided=xp.host(self.collided), viable=xp.host(self.viable), abort_events=self._abort_events)
+                    collided=xp.host(self.collided), viable=xp.host(self.viable),
+                    abort_events=[(e[0], e[1], e[2] if isinstance(e[2], np.ndarray) else xp.host(e[2])) for e in self._abort_events])
 
 
 def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, make_controller=None, make_backup=None,

@@ -53,6 +53,8 @@ struct smpc_handle {
     // MLP activations
     size_t capM = 0;
     float *d_S = nullptr, *d_y = nullptr, *d_GS = nullptr, *d_dA = nullptr, *d_dB = nullptr;
+    int32_t *d_nn_idx = nullptr, *d_nn_cnt = nullptr;   // compacted list of the nodes whose safe-set row is on + its length
+    size_t nn_idx_cap = 0;
     float* d_act[SMPC_MAX_LAYERS] = {nullptr};
     float* d_dg[SMPC_MAX_LAYERS] = {nullptr};
     // generic scratch for the caller entry points
@@ -196,43 +198,47 @@ int ensure_mlp(smpc_handle* h, size_t M) {
     return SMPC_OK;
 }
 
-// forward (and optionally backward) pass of the network over M rows whose states are found through (mode, N) in x
+// forward (and optionally backward) pass of the network over M rows whose states are found through (mode, N) in x.
+// mode 3: the rows are the compacted list h->d_nn_idx of live nodes; their count is only known on the device (h->d_nn_cnt), so
+// the grids cover all M candidate rows and the blocks past the count return at once.
 template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const double* d_x, bool backward) {
     int rc;
     if ((rc = ensure_mlp(h, (size_t)M))) return rc;
     const int Mp = (M + 127) / 128 * 128, H = h->H, L = h->nlayers;
     hipStream_t s = h->stream;
+    const int32_t* idx = mode == 3 ? h->d_nn_idx : nullptr;
+    const int32_t* live = mode == 3 ? h->d_nn_cnt : nullptr;
     hipLaunchKernelGGL((k_nn_features<NQ>), dim3((Mp + 255) / 256), dim3(256), 0, s, h->d_desc, M, Mp, N, mode, d_x,
-                       h->d_S);
+                       h->d_S, idx, live);
     const dim3 blk(256), grd(Mp / 128, H / 64);
     hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, MLP_KPAD, h->d_S, h->d_Wfwd[0], h->d_bias[0],
-                       (const float*)nullptr, h->d_act[0], h->d_dg[0]);
+                       (const float*)nullptr, h->d_act[0], h->d_dg[0], live);
     // hidden x hidden layers: LDS-tiled kernel once there are enough 128 x 128 tiles to fill the chip
     const bool tiled = Mp >= 8192 && H % 128 == 0;
     const dim3 grd_t(Mp / 128, H / 128);
     for (int l = 1; l + 1 < L; l++) {
         if (tiled)
             hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_BIAS_GELU>), grd_t, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
-                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l]);
+                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live);
         else
             hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
-                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l]);
+                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live);
     }
     hipLaunchKernelGGL(k_nn_output, dim3((Mp + 3) / 4), blk, 0, s, Mp, H, h->d_act[L - 2], h->d_dg[L - 2],
-                       h->d_Wbwd[L - 1], h->d_bias[L - 1], h->d_y, h->d_dA);
+                       h->d_Wbwd[L - 1], h->d_bias[L - 1], h->d_y, h->d_dA, live);
     if (backward) {
         float *cur = h->d_dA, *nxt = h->d_dB;
         for (int l = L - 2; l >= 1; l--) {
             if (tiled)
                 hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_MUL>), grd_t, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l],
-                                   (const float*)nullptr, h->d_dg[l - 1], nxt, (float*)nullptr);
+                                   (const float*)nullptr, h->d_dg[l - 1], nxt, (float*)nullptr, live);
             else
                 hipLaunchKernelGGL((k_gemm_f32<EPI_MUL>), grd, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l], (const float*)nullptr,
-                                   h->d_dg[l - 1], nxt, (float*)nullptr);
+                                   h->d_dg[l - 1], nxt, (float*)nullptr, live);
             float* t = cur; cur = nxt; nxt = t;
         }
         hipLaunchKernelGGL((k_gemm_f32<EPI_PLAIN>), dim3(Mp / 128, MLP_NPAD / 64), blk, 0, s, Mp, MLP_NPAD, H, cur,
-                           h->d_Wbwd[0], (const float*)nullptr, (const float*)nullptr, h->d_GS, (float*)nullptr);
+                           h->d_Wbwd[0], (const float*)nullptr, (const float*)nullptr, h->d_GS, (float*)nullptr, live);
     }
     HIPCHK(h, hipGetLastError());
     return SMPC_OK;
@@ -251,12 +257,24 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
     if (h->desc.nn_mode != SMPC_NN_NONE) {
         if (h->nlayers == 0) return fail(h, SMPC_ESTATE, "nn_mode != NONE but smpc_set_mlp was not called");
-        const int mode = h->desc.nn_mode == SMPC_NN_TERMINAL ? 1 : 2;
+        // row on every node: only the nodes whose per-node switch is on are evaluated (compacted list, mode 3)
+        const int mode = h->desc.nn_mode == SMPC_NN_TERMINAL ? 1 : 3;
         const int M = mode == 1 ? B : B * N;
         int rc;
+        if (mode == 3) {
+            if ((size_t)M > h->nn_idx_cap) {
+                HIPCHK(h, hipStreamSynchronize(s));
+                if ((rc = dev_alloc(h, &h->d_nn_idx, (size_t)M + 1))) return rc;
+                h->nn_idx_cap = (size_t)M;
+                h->d_nn_cnt = h->d_nn_idx + M;
+            }
+            HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_nn_compact, dim3((M + 255) / 256), dim3(256), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
+        }
         if ((rc = run_mlp<NQ>(h, M, mode, N, d_xg, true))) return rc;
         hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 255) / 256), dim3(256), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
-                           h->d_y, h->d_GS, d_ev);
+                           h->d_y, h->d_GS, d_ev, mode == 3 ? h->d_nn_idx : (const int32_t*)nullptr,
+                           mode == 3 ? h->d_nn_cnt : (const int32_t*)nullptr);
         HIPCHK(h, hipGetLastError());
     }
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[2], s));
@@ -503,6 +521,7 @@ void smpc_destroy(smpc_handle* h) {
     for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
     if (h->d_pol) (void)hipFree(h->d_pol);
     if (h->d_polw) (void)hipFree(h->d_polw);
+    if (h->d_nn_idx) (void)hipFree(h->d_nn_idx);
     if (h->d_roll) (void)hipFree(h->d_roll);
     if (h->d_chk) (void)hipFree(h->d_chk);
     if (h->d_wstat) (void)hipFree(h->d_wstat);

@@ -39,11 +39,12 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const float* __restrict__ A,
                                                   const float* __restrict__ Bm, const float* __restrict__ bias,
                                                   const float* __restrict__ aux, float* __restrict__ out1,
-                                                  float* __restrict__ out2) {
+                                                  float* __restrict__ out2, const int32_t* __restrict__ m_live) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m0 = (blockIdx.x * 4 + wave) * 32;
     const int n0 = blockIdx.y * 64;
     if (m0 >= M) return;
+    if (m_live && m0 >= *m_live) return;   // (rows past the live count of a compacted list: nothing to compute)
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc0, acc1;
 #pragma unroll
@@ -115,12 +116,13 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f32_tiled(int M, int N, int K, const float* __restrict__ A,
                                                         const float* __restrict__ Bm, const float* __restrict__ bias,
                                                         const float* __restrict__ aux, float* __restrict__ out1,
-                                                        float* __restrict__ out2) {
+                                                        float* __restrict__ out2, const int32_t* __restrict__ m_live) {
     constexpr int TM = 128, TN = 128, TK = 16, AS = TK + 1, BS = TN + 32;   // row strides: conflict-free column / row reads
     __shared__ float As[2][TM * AS];
     __shared__ __attribute__((aligned(16))) float Bs[2][TK * BS];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63, li = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    if (m_live && m0 >= *m_live) return;   // (whole block: uniform, before the first barrier)
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     f32x16 acc[2][2];
 #pragma unroll
@@ -195,22 +197,37 @@ __global__ __launch_bounds__(256) void k_gemm_f32_tiled(int M, int N, int K, con
 
 // features of the safe-set network (safe_set.py:82-87): s = [(q - mean)/std ; v/|v|], v = qd with eps on v_0.
 // row m <-> node:  mode 0: node = m (plain list of states);  mode 1 (terminal): node = m (N+1) + N;
-//                  mode 2 (all nodes but the first): b = m / N, k = 1 + m % N.
-__device__ __forceinline__ long nn_row_to_node(int mode, int N, int m) {
+//                  mode 2 (all nodes but the first): b = m / N, k = 1 + m % N;
+//                  mode 3: node = idx[m] for m < *m_live -- the nodes of mode 2 whose row is switched on (k_nn_compact).
+__device__ __forceinline__ long nn_row_to_node(int mode, int N, int m, const int32_t* __restrict__ idx = nullptr) {
     if (mode == 0) return m;
     if (mode == 1) return (long)m * (N + 1) + N;
+    if (mode == 3) return idx[m];
     return (long)(m / N) * (N + 1) + 1 + m % N;
+}
+
+// The per-node switch of the safe-set row (utils.py:207-210, p[4] of the node): the receding policy carries the row at two
+// nodes per instance (controller.py:452-469), so the network is evaluated on the list of live nodes only.  The order of the
+// list is whatever the atomics give; every row's result is independent of its position.
+__global__ void k_nn_compact(int M, int N, const double* __restrict__ p, int32_t* __restrict__ idx, int32_t* __restrict__ m_live) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const long node = nn_row_to_node(2, N, m);
+    if (p[node * SMPC_NP + 4] > 0.0) idx[atomicAdd(m_live, 1)] = (int32_t)node;
 }
 template <int NQ>
 __global__ void k_nn_features(const smpc_problem_desc* __restrict__ D, int M, int Mpad, int N, int mode,
-                              const double* __restrict__ xg, float* __restrict__ S) {
+                              const double* __restrict__ xg, float* __restrict__ S, const int32_t* __restrict__ idx,
+                              const int32_t* __restrict__ m_live) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= Mpad) return;
+    const int live = m_live ? *m_live : M;
+    if (m >= ((live + 127) & ~127)) return;      // (only the tiles that will be computed need defined rows)
     float* s = S + (size_t)m * MLP_KPAD;
 #pragma unroll
     for (int i = 0; i < MLP_KPAD; i++) s[i] = 0.0f;
-    if (m >= M) return;
-    const double* x = xg + nn_row_to_node(mode, N, m) * (2 * NQ);
+    if (m >= live) return;
+    const double* x = xg + nn_row_to_node(mode, N, m, idx) * (2 * NQ);
     const int nd = D->nn_dof;
     double v[NQ], vn2 = 0.0;
 #pragma unroll
@@ -231,10 +248,12 @@ __global__ void k_nn_features(const smpc_problem_desc* __restrict__ D, int M, in
 // output layer y = a . w + b  and  delta = w (.) gelu'(z) of the last hidden layer; one wave per row
 __global__ __launch_bounds__(256) void k_nn_output(int M, int H, const float* __restrict__ A, const float* __restrict__ Dg,
                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ y, float* __restrict__ delta) {
+                                                   float* __restrict__ y, float* __restrict__ delta,
+                                                   const int32_t* __restrict__ m_live) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
+    if (m_live && row >= ((*m_live + 127) & ~127)) return;
     float acc = 0.0f;
     for (int c = lane; c < H; c += 64) {
         const size_t o = (size_t)row * H + c;
@@ -250,10 +269,12 @@ __global__ __launch_bounds__(256) void k_nn_output(int M, int H, const float* __
 template <int NQ>
 __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N, int mode,
                            const double* __restrict__ xg, const double* __restrict__ p, const float* __restrict__ y,
-                           const float* __restrict__ GS, smpc_node_eval* __restrict__ out) {
+                           const float* __restrict__ GS, smpc_node_eval* __restrict__ out, const int32_t* __restrict__ idx,
+                           const int32_t* __restrict__ m_live) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const long node = nn_row_to_node(mode, N, m);
+    if (m_live && m >= *m_live) return;
+    const long node = nn_row_to_node(mode, N, m, idx);
     const double* x = xg + node * (2 * NQ);
     const double* pk = p + node * SMPC_NP;
     smpc_node_eval* o = out + node;
