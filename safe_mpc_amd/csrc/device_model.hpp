@@ -6,11 +6,35 @@
 // accumulated on the fly (no stored per-link forces).  Replaces the adam/CasADi graphs of the reference
 // (src/safe_mpc/env_model.py:40-45, 80-83, 92-95, 131-163) -- N1/N2 in SURVEY section 2.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 
 #include "../../include/smpc.h"
 
 namespace smpc {
+
+// ---- node records in HBM: interleaved tiles of EV_TILE nodes --------------------------------------------------------------------
+// The linearisation kernels are thread-per-node, and a thread that stores one double into its own node's 2.6 KB record makes the
+// wave write 64 scattered 8-byte pieces: measured, HBM then sees 4 x the bytes (446 MB per launch for 112 MB of torque
+// Jacobians: writes go out in 32-byte sectors; profiles/r02_kernel_sheet_before_tiles.txt).  So the records of EV_TILE
+// consecutive nodes are interleaved element by element -- element f of node n sits at
+// (n / EV_TILE) * EV_TILE * EV_D + f * EV_TILE + n % EV_TILE -- and EV_TILE neighbouring lanes fill whole sectors per store.
+// k_qp_setup loads a tile with one block (EV_TILE half-waves, one node each) and takes it apart in LDS; smpc_eval_nodes returns
+// plain smpc_node_eval records (k_ev_untile).  EV_TILE = 4 (one 32-byte sector per store group): with 8 the producers gain
+// nothing more, and k_qp_setup's 46 KB blocks no longer fit next to the resident QP wavefronts (148 KB of LDS per CU) -- in the
+// three-stream closed loop it ran 2.2 x longer and the step 3 % slower; 2 / 4 / 8: 3.89 / 3.85 / 4.02 ms per step against 3.90
+// with plain records (three alternations in one session).
+constexpr int EV_D = (int)(sizeof(smpc_node_eval) / sizeof(double));
+#ifndef SMPC_EV_TILE
+#define SMPC_EV_TILE 4
+#endif
+constexpr int EV_TILE = SMPC_EV_TILE;
+#define SMPC_EV_OFF(field) ((int)(offsetof(smpc_node_eval, field) / sizeof(double)))
+__host__ __device__ inline size_t ev_tiles(size_t nodes) { return (nodes + EV_TILE - 1) / EV_TILE; }
+// pointer to element 0 of node n's record; element f is at [f * EV_TILE]
+__device__ __forceinline__ double* ev_node(double* base, long n) { return base + (n / EV_TILE) * (EV_TILE * (long)EV_D) + n % EV_TILE; }
+__device__ __forceinline__ const double* ev_node(const double* base, long n) { return base + (n / EV_TILE) * (EV_TILE * (long)EV_D) + n % EV_TILE; }
+
 
 // ---- scalar with one tangent direction ------------------------------------------------------------------------------
 struct D1 {

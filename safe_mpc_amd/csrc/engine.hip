@@ -41,7 +41,7 @@ struct smpc_handle {
     float* d_bias[SMPC_MAX_LAYERS] = {nullptr};
     // per-batch scratch, grown on demand
     int capB = 0;
-    smpc_node_eval* d_ev = nullptr;
+    double* d_ev = nullptr;       // linearisation records of the last call, 8-node interleaved tiles (device_model.hpp)
     double* d_ws = nullptr;
     size_t ws_bytes = 0;
     int32_t *d_order = nullptr, *d_last_it = nullptr;  // longest-first dispatch order from the previous call's iterations
@@ -140,7 +140,7 @@ int ensure_batch(smpc_handle* h, int B) {
     if (B > h->capB || need > h->ws_bytes) {
         int rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if ((rc = dev_alloc(h, &h->d_ev, (size_t)B * (h->N + 1)))) return rc;
+        if ((rc = dev_alloc(h, &h->d_ev, ev_tiles((size_t)B * (h->N + 1)) * EV_TILE * EV_D))) return rc;
         if ((rc = dev_alloc(h, &h->d_ws, per * (size_t)B))) return rc;
         if ((rc = dev_alloc(h, &h->d_order, (size_t)B))) return rc;
         if ((rc = dev_alloc(h, &h->d_last_it, (size_t)B))) return rc;
@@ -245,13 +245,13 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
 }
 
 template <int NQ>
-int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, const double* d_p, smpc_node_eval* d_ev) {
+int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, const double* d_p, double* d_ev) {
     const int N = h->N;
     hipStream_t s = h->stream;
-    const long n1 = (long)B * (N + 1), n2 = (long)B * N;
+    const long n1 = (long)B * (N + 1);
     hipLaunchKernelGGL((k_node_geometry<NQ>), dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, s, h->d_desc, B, N, d_xg,
                        d_p, d_ev);
-    hipLaunchKernelGGL((k_node_torque<NQ>), dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg, d_ug,
+    hipLaunchKernelGGL((k_node_torque<NQ>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg, d_ug,
                        d_ev);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
@@ -305,7 +305,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         hipLaunchKernelGGL(k_order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->d_last_it, h->d_order);
         order = h->d_order;
     }
-    const int pairs = (int)(((long)B * (h->N + 1) + 1) / 2);
+    const int tiles = (int)ev_tiles((size_t)B * (h->N + 1));
     unsigned long long* wstat = nullptr;
     if (h->timing) {
         if (!h->d_wstat) HIPCHK(h, hipMalloc((void**)&h->d_wstat, 4 * sizeof(unsigned long long)));
@@ -317,7 +317,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     // pairs, config.yaml:205-216; 4: config_fr7.yaml); any other count takes the runtime-row-count instantiation
 #define SMPC_QP_LAUNCH(MR_)                                                                                                        \
     do {                                                                                                                           \
-        hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(pairs), dim3(64), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
+        hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
                            bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                                  \
         if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                           \
         hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
@@ -663,20 +663,29 @@ int smpc_eval_nodes(smpc_handle* h, int B, const double* xg, const double* ug, c
     int rc;
     if ((rc = ensure_batch(h, B))) return rc;
     const int N = h->N, nx = 2 * h->desc.nq, nu = h->desc.nq;
-    if (on_device) {
-        DISPATCH_NQ(h, (launch_eval<NQ_>(h, B, xg, ug, p, out)));
-        return rc;
-    }
-    if ((rc = ensure_io(h, B))) return rc;
     hipStream_t s = h->stream;
-    HIPCHK(h, hipMemcpyAsync(h->d_xg, xg, sizeof(double) * B * (N + 1) * nx, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_ug, ug, sizeof(double) * B * N * nu, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_p, p, sizeof(double) * B * (N + 1) * SMPC_NP, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemsetAsync(h->d_ev, 0, sizeof(smpc_node_eval) * (size_t)B * (N + 1), s));
-    DISPATCH_NQ(h, (launch_eval<NQ_>(h, B, h->d_xg, h->d_ug, h->d_p, h->d_ev)));
+    const long nodes = (long)B * (N + 1);
+    const double *dxg = xg, *dug = ug, *dp = p;
+    double* dout = reinterpret_cast<double*>(out);
+    if (!on_device) {
+        if ((rc = ensure_io(h, B))) return rc;
+        if ((rc = ensure_tmp(h, sizeof(smpc_node_eval) * (size_t)nodes))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->d_xg, xg, sizeof(double) * B * (N + 1) * nx, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->d_ug, ug, sizeof(double) * B * N * nu, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->d_p, p, sizeof(double) * B * (N + 1) * SMPC_NP, hipMemcpyHostToDevice, s));
+        dxg = h->d_xg; dug = h->d_ug; dp = h->d_p;
+        dout = (double*)h->d_tmp;
+    }
+    // (entries no kernel writes -- the unused tails of the MAX_NQ / MAX_ROWS arrays -- read as zero)
+    HIPCHK(h, hipMemsetAsync(h->d_ev, 0, sizeof(double) * ev_tiles((size_t)nodes) * EV_TILE * EV_D, s));
+    DISPATCH_NQ(h, (launch_eval<NQ_>(h, B, dxg, dug, dp, h->d_ev)));
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(out, h->d_ev, sizeof(smpc_node_eval) * (size_t)B * (N + 1), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_ev_untile, dim3((unsigned)((nodes * EV_D + 255) / 256)), dim3(256), 0, s, nodes, h->d_ev, dout);
+    HIPCHK(h, hipGetLastError());
+    if (!on_device) {
+        HIPCHK(h, hipMemcpyAsync(out, dout, sizeof(smpc_node_eval) * (size_t)nodes, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
     return SMPC_OK;
 }
 
@@ -1141,36 +1150,6 @@ int smpc_get_qp_wave_stats(smpc_handle* h, double* out3) {
 }
 
 }  // extern "C"
-
-// Diagnostic entry (not part of include/smpc.h): times k_node_torque with its outputs in the node records (mode 0) or field-major
-// across the batch axis (mode 1) on device-resident xg / ug; ms = average of `reps` launches.
-extern "C" int smpc_debug_torque_layout(smpc_handle* h, int B, const double* xg, const double* ug, int mode, int reps, float* ms) {
-    if (!h || h->desc.nq != 6) return SMPC_EINVAL;
-    (void)hipSetDevice(h->device);
-    int rc;
-    if ((rc = ensure_batch(h, B))) return rc;
-    const long n = (long)B * h->N;
-    double* soa = nullptr;
-    if (mode == 1 && hipMalloc((void**)&soa, sizeof(double) * n * (6 + 3 * 36)) != hipSuccess) return SMPC_ENOMEM;
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
-    for (int i = 0; i < reps + 1; i++) {
-        if (i == 1) (void)hipEventRecord(e0, h->stream);
-        if (mode == 0)
-            hipLaunchKernelGGL((k_node_torque<6>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_desc, B, h->N, xg, ug, h->d_ev);
-        else
-            hipLaunchKernelGGL((k_node_torque_soa<6>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, h->d_desc, B, h->N, xg, ug, soa);
-    }
-    (void)hipEventRecord(e1, h->stream);
-    (void)hipEventSynchronize(e1);
-    (void)hipEventElapsedTime(ms, e0, e1);
-    *ms /= (float)reps;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (soa) (void)hipFree(soa);
-    return SMPC_OK;
-}
 
 #ifdef QP_PROFILE
 // diagnostic builds only (not part of include/smpc.h): per-phase shader-clock sums of k_qp_ipm since the last call

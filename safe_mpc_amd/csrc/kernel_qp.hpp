@@ -296,21 +296,37 @@ __device__ unsigned long long g_qp_prof[16];
 
 
 // =========================================================================================================================
-// k_qp_setup: stage records + initial interior point, one half-wave per (instance, stage)
+// k_qp_setup: stage records + initial interior point, one half-wave per (instance, stage); a block = the 8 nodes of one
+// interleaved tile of linearisation records (device_model.hpp), loaded by all its threads and taken apart in LDS
 // =========================================================================================================================
 template <int NQ, int MRT>
-__global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __restrict__ D, int B, int N,
-                                                 const double* __restrict__ x0, const double* __restrict__ xg,
-                                                 const double* __restrict__ ug, const double* __restrict__ pp,
-                                                 const double* __restrict__ lo_st, const double* __restrict__ hi_st,
-                                                 const double* __restrict__ zl_st, const smpc_node_eval* __restrict__ ev, double* __restrict__ ws_all,
-                                                 long bnd_stride, const uint8_t* __restrict__ active) {
+__global__ __launch_bounds__(32 * EV_TILE) void k_qp_setup(const smpc_problem_desc* __restrict__ D, int B, int N,
+                                                  const double* __restrict__ x0, const double* __restrict__ xg,
+                                                  const double* __restrict__ ug, const double* __restrict__ pp,
+                                                  const double* __restrict__ lo_st, const double* __restrict__ hi_st,
+                                                  const double* __restrict__ zl_st, const double* __restrict__ ev, double* __restrict__ ws_all,
+                                                  long bnd_stride, const uint8_t* __restrict__ active) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, NL = 32;
     constexpr int MAXRC = NQ + (MRT >= 0 ? MRT : SMPC_MAX_ROWS) + 1;
-    constexpr int EV_D = (int)(sizeof(smpc_node_eval) / sizeof(double)), EV_PAD = qp_even_c(EV_D);
+    constexpr int EV_PAD = qp_even_c(EV_D);
     const int hl = threadIdx.x & 31, half = threadIdx.x >> 5;
-    const long pi = 2L * blockIdx.x + half;
+    constexpr int O_C = EV_PAD, O_LO = O_C + MAXRC * NZP, O_HI = O_LO + NL, O_E = O_HI + NL, O_Z0 = O_E + NL, O_GZ = O_Z0 + NL,
+                  O_B = O_GZ + NZP, HALF_D = O_B + NX;
+    __shared__ __attribute__((aligned(16))) double smem[EV_TILE * HALF_D];
+    static_assert(EV_TILE % 2 == 0 && EV_TILE <= 32, "one half-wave per node of a tile");
+    {
+        // the tile: EV_TILE * EV_D doubles, contiguous; piece p holds element (2p) / 8 of nodes (2p) % 8 and (2p) % 8 + 1
+        const dbl2* s2 = reinterpret_cast<const dbl2*>(ev + (size_t)blockIdx.x * (EV_TILE * EV_D));
+        for (int p2 = threadIdx.x; p2 < EV_TILE * EV_D / 2; p2 += 32 * EV_TILE) {
+            const dbl2 v = ldnt_su(s2 + p2);
+            const int f = (2 * p2) / EV_TILE, n = (2 * p2) % EV_TILE;
+            smem[n * HALF_D + f] = v.x;
+            smem[(n + 1) * HALF_D + f] = v.y;
+        }
+    }
+    __syncthreads();
+    const long pi = (long)EV_TILE * blockIdx.x + half;
     if (pi >= (long)B * (N + 1)) return;
     const int b = (int)(pi / (N + 1)), k = (int)(pi - (long)b * (N + 1));
     if (active && !active[b]) return;   // (policy layer: this instance does not step its controller; k_qp_ipm skips it too)
@@ -320,9 +336,6 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
     double* w = ws_all + (size_t)b * Ly.per_instance(N) + (size_t)k * Ly.stride;
     const double dt = D->dt, cB = 0.5 * dt * dt;
 
-    constexpr int O_C = EV_PAD, O_LO = O_C + MAXRC * NZP, O_HI = O_LO + NL, O_E = O_HI + NL, O_Z0 = O_E + NL, O_GZ = O_Z0 + NL,
-                  O_B = O_GZ + NZP, HALF_D = O_B + NX;
-    __shared__ __attribute__((aligned(16))) double smem[2 * HALF_D];
     double* const sEV = smem + half * HALF_D;
     double* const sC = sEV + O_C;
     double* const sLO = sEV + O_LO;
@@ -335,11 +348,6 @@ __global__ __launch_bounds__(64) void k_qp_setup(const smpc_problem_desc* __rest
     const double* xk = xg + ((size_t)b * (N + 1) + k) * NX;
     const double* pk = pp + ((size_t)b * (N + 1) + k) * SMPC_NP;
     const bool last = (k == N);
-    {
-        const dbl2* s2 = reinterpret_cast<const dbl2*>(ev + (size_t)b * (N + 1) + k);
-        dbl2* d2 = reinterpret_cast<dbl2*>(sEV);
-        for (int i = hl; i < EV_D / 2; i += 32) d2[i] = ldnt_su(s2 + i);
-    }
     // z = 0 except the fixed dx_0
     sZ0[hl] = (k == 0 && hl >= NU && hl < NZ) ? x0[(size_t)b * NX + hl - NU] - xk[hl - NU] : 0.0;
     lds_fence();

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_nn_output(int M, int H, const float* __
 template <int NQ>
 __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N, int mode,
                            const double* __restrict__ xg, const double* __restrict__ p, const float* __restrict__ y,
-                           const float* __restrict__ GS, smpc_node_eval* __restrict__ out, const int32_t* __restrict__ idx,
+                           const float* __restrict__ GS, double* __restrict__ out, const int32_t* __restrict__ idx,
                            const int32_t* __restrict__ m_live) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
@@ -277,7 +277,7 @@ __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N
     const long node = nn_row_to_node(mode, N, m, idx);
     const double* x = xg + node * (2 * NQ);
     const double* pk = p + node * SMPC_NP;
-    smpc_node_eval* o = out + node;
+    double* const o = ev_node(out, node);          // (interleaved tile: element f at o[f * EV_TILE])
     if (!(pk[4] > 0.0)) return;  // switched off: row sits mid-bounds, leave (0, 0)
     const int nd = D->nn_dof;
     const float* gs = GS + (size_t)m * MLP_NPAD;
@@ -292,12 +292,12 @@ __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N
     for (int i = 0; i < NQ; i++)
         if (i < nd) gdv += (double)gs[nd + i] * v[i];
     const double kap = (100.0 - pk[3]) / 100.0;
-    o->nn_val = (double)y[m] * kap - vn;
+    o[SMPC_EV_OFF(nn_val) * EV_TILE] = (double)y[m] * kap - vn;
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         if (i < nd) {
-            o->nn_grad[i] = kap * (double)gs[i] / D->nn_std[i];
-            o->nn_grad[NQ + i] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
+            o[(SMPC_EV_OFF(nn_grad) + i) * EV_TILE] = kap * (double)gs[i] / D->nn_std[i];
+            o[(SMPC_EV_OFF(nn_grad) + NQ + i) * EV_TILE] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
         }
     }
 }

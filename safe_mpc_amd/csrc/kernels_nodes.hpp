@@ -12,13 +12,17 @@ namespace smpc {
 template <int NQ>
 __global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* __restrict__ D, int B, int N,
                                                        const double* __restrict__ xg, const double* __restrict__ p,
-                                                       smpc_node_eval* __restrict__ out) {
+                                                       double* __restrict__ out) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)B * (N + 1)) return;
     constexpr int NX = 2 * NQ;
     const double* x = xg + t * NX;
     const double* pk = p + t * SMPC_NP;
-    smpc_node_eval* o = out + t;
+    double* const o = ev_node(out, t);          // (interleaved tile: element f at o[f * EV_TILE])
+    auto put = [&](int f, double v) { o[f * EV_TILE] = v; };
+    constexpr int F_EE = SMPC_EV_OFF(ee), F_CG = SMPC_EV_OFF(cost_grad_q), F_CH = SMPC_EV_OFF(cost_hess_qq), F_RV = SMPC_EV_OFF(row_val),
+                  F_RG = SMPC_EV_OFF(row_grad), F_NV = SMPC_EV_OFF(nn_val), F_NG = SMPC_EV_OFF(nn_grad), F_TAU = SMPC_EV_OFF(tau),
+                  F_M = SMPC_EV_OFF(M), F_DQ = SMPC_EV_OFF(dtau_dq), F_DV = SMPC_EV_OFF(dtau_dv);
 
     double q[NQ];
 #pragma unroll
@@ -30,7 +34,7 @@ __global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* 
     // EE point, cost gradient and Hessian (cost_definition.py:69-96)
     {
         DV3<NQ> ee = point_with_jacobian<NQ>(D->points[D->ee_point], Rw, pw, zw);
-        o->ee[0] = ee.x.v; o->ee[1] = ee.y.v; o->ee[2] = ee.z.v;
+        put(F_EE, ee.x.v); put(F_EE + 1, ee.y.v); put(F_EE + 2, ee.z.v);
         if (D->cost_kind == SMPC_COST_REACH) {
             const double Q2 = 2.0 * D->Q;
             const double dx = ee.x.v - pk[0], dy = ee.y.v - pk[1], dz = ee.z.v - pk[2];
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* 
             Vec3<double> P(ee.x.v, ee.y.v, ee.z.v), del(dx, dy, dz);
 #pragma unroll
             for (int i = 0; i < NQ; i++) {
-                o->cost_grad_q[i] = Q2 * (ee.x.d[i] * dx + ee.y.d[i] * dy + ee.z.d[i] * dz);
+                put(F_CG + i, Q2 * (ee.x.d[i] * dx + ee.y.d[i] * dy + ee.z.d[i] * dz));
 #pragma unroll
                 for (int j = 0; j < NQ; j++) {
                     double h = ee.x.d[i] * ee.x.d[j] + ee.y.d[i] * ee.y.d[j] + ee.z.d[i] * ee.z.d[j];
@@ -50,15 +54,15 @@ __global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* 
                             h += dot(del, cross(zw[lo], Jhi));
                         }
                     }
-                    o->cost_hess_qq[i * NQ + j] = Q2 * h;
+                    put(F_CH + i * NQ + j, Q2 * h);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NQ; i++) {
-                o->cost_grad_q[i] = 0.0;
+                put(F_CG + i, 0.0);
 #pragma unroll
-                for (int j = 0; j < NQ; j++) o->cost_hess_qq[i * NQ + j] = 0.0;
+                for (int j = 0; j < NQ; j++) put(F_CH + i * NQ + j, 0.0);
             }
         }
     }
@@ -96,45 +100,47 @@ __global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* 
             break;
         }
         }
-        o->row_val[r] = v.v;
+        put(F_RV + r, v.v);
 #pragma unroll
-        for (int i = 0; i < NQ; i++) o->row_grad[r * NQ + i] = v.d[i];
+        for (int i = 0; i < NQ; i++) put(F_RG + r * NQ + i, v.d[i]);
     }
     // fields owned by other kernels start from a defined value
-    o->nn_val = 0.0;
+    put(F_NV, 0.0);
 #pragma unroll
-    for (int i = 0; i < NX; i++) o->nn_grad[i] = 0.0;
+    for (int i = 0; i < NX; i++) put(F_NG + i, 0.0);
     const int k = (int)(t % (N + 1));
     if (k == N) {
 #pragma unroll
         for (int i = 0; i < NQ; i++) {
-            o->tau[i] = 0.0;
+            put(F_TAU + i, 0.0);
 #pragma unroll
             for (int j = 0; j < NQ; j++) {
-                o->M[i * NQ + j] = 0.0;
-                o->dtau_dq[i * NQ + j] = 0.0;
-                o->dtau_dv[i * NQ + j] = 0.0;
+                put(F_M + i * NQ + j, 0.0);
+                put(F_DQ + i * NQ + j, 0.0);
+                put(F_DV + i * NQ + j, 0.0);
             }
         }
     }
 }
 
-// ---- K2: torque row and Jacobians, one thread per (b, k < N) ---------------------------------------------------------------
+// ---- K2: torque row and Jacobians, one thread per (b, k) ------------------------------------------------------------------------
 // One forward and one backward recursion give tau, M = dtau/du, dtau/dq and dtau/dqd in closed form (rnea_deriv.hpp); every
-// entry is stored once, straight from the recursion into the node's record.  (Round 1 ran 3 NQ single-tangent dual-number
-// passes per node in 3 NQ threads: 0.48 ms per 4096 x 30 nodes.)
+// entry is stored once, straight from the recursion into the node's (interleaved) record.  The thread index runs over ALL nodes,
+// so that 8 neighbouring lanes always belong to one tile; the terminal nodes (no torque row) idle.  (Round 1 ran 3 NQ
+// single-tangent dual-number passes per node in 3 NQ threads: 0.48 ms per 4096 x 30 nodes.)
 template <int NQ>
 __global__ __launch_bounds__(64) void k_node_torque(const smpc_problem_desc* __restrict__ D, int B, int N,
                                                     const double* __restrict__ xg, const double* __restrict__ ug,
-                                                    smpc_node_eval* __restrict__ out) {
+                                                    double* __restrict__ out) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)B * N) return;
+    if (t >= (long)B * (N + 1)) return;
     constexpr int NX = 2 * NQ;
-    const long b = t / N;
-    const int k = (int)(t % N);
-    const double* x = xg + (b * (N + 1) + k) * NX;
-    const double* u = ug + t * NQ;
-    smpc_node_eval* o = out + b * (N + 1) + k;
+    const long b = t / (N + 1);
+    const int k = (int)(t - b * (N + 1));
+    if (k == N) return;
+    const double* x = xg + t * NX;
+    const double* u = ug + (b * N + k) * NQ;
+    double* const o = ev_node(out, t);
     double q[NQ], qd[NQ], qdd[NQ];
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
@@ -142,34 +148,17 @@ __global__ __launch_bounds__(64) void k_node_torque(const smpc_problem_desc* __r
         qd[i] = x[NQ + i];
         qdd[i] = u[i];
     }
-    rd::rnea_with_derivatives<NQ>(D->joints, D->gravity, q, qd, qdd, o->tau, o->M, o->dtau_dq, o->dtau_dv);
+    rd::rnea_with_derivatives<NQ>(D->joints, D->gravity, q, qd, qdd, o + SMPC_EV_OFF(tau) * EV_TILE, o + SMPC_EV_OFF(M) * EV_TILE,
+                                  o + SMPC_EV_OFF(dtau_dq) * EV_TILE, o + SMPC_EV_OFF(dtau_dv) * EV_TILE, (long)EV_TILE);
 }
 
-// Layout experiment (diagnostic entry smpc_debug_torque_layout): the same work with the outputs written
-// field-major across the batch axis -- out[f][node], consecutive lanes to consecutive addresses -- instead of into each node's
-// 2.6 KB record.
-template <int NQ>
-__global__ __launch_bounds__(64) void k_node_torque_soa(const smpc_problem_desc* __restrict__ D, int B, int N,
-                                                        const double* __restrict__ xg, const double* __restrict__ ug,
-                                                        double* __restrict__ out) {
+// smpc_eval_nodes: the interleaved tiles back into plain records, one thread per (node, element)
+__global__ void k_ev_untile(long nodes, const double* __restrict__ tiled, double* __restrict__ plain) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n = (long)B * N;
-    if (t >= n) return;
-    constexpr int NX = 2 * NQ;
-    const long b = t / N;
-    const int k = (int)(t % N);
-    const double* x = xg + (b * (N + 1) + k) * NX;
-    const double* u = ug + t * NQ;
-    double q[NQ], qd[NQ], qdd[NQ];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        q[i] = x[i];
-        qd[i] = x[NQ + i];
-        qdd[i] = u[i];
-    }
-    double* o = out + t;
-    rd::rnea_with_derivatives<NQ>(D->joints, D->gravity, q, qd, qdd, o, o + (long)NQ * n, o + (long)(NQ + NQ * NQ) * n,
-                                  o + (long)(NQ + 2 * NQ * NQ) * n, n);
+    if (t >= nodes * EV_D) return;
+    const long n = t / EV_D;
+    const int f = (int)(t - n * EV_D);
+    plain[t] = ev_node(tiled, n)[f * EV_TILE];
 }
 
 }  // namespace smpc
