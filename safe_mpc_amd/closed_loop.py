@@ -400,6 +400,10 @@ class _Group(InPlaceState):
             xo_c, uo_c, st_c, _ = backup.ocp_solver.solve(xv_c, xg_c, xp.zeros((n_c, Nb, ctrl.nu)), backup.p[:n_c])
             ev = torch.cuda.Event()
             ev.record(self._side)
+        # (These tensors cross streams.  Their lifetimes are ordered by the events, not by the caching allocator: they are released
+        #  in _apply_inflight, after the main stream has been told to wait for `ev`, and the side stream's next work waits for an
+        #  event recorded on the main stream after that.  torch's record_stream is not usable here -- on this ROCm build it
+        #  faults on an ExternalStream.)
         self._inflight = (rows_b, xv_c, xo_c, uo_c, st_c, ev)
 
     # ---- second half: plant, outcome tests, logs ----------------------------------------------------------------------------------

@@ -535,6 +535,39 @@ def test_device_policy_loop_at_bench_size_invariants():
     assert np.isfinite(u[~unan]).all()
 
 
+def test_policy_entry_points_reject_misuse():
+    """API misuse of the policy entry points comes back as a negative code with text, never as a launch on bad pointers."""
+    import ctypes as C
+    import torch
+    from safe_mpc_amd import _lib
+    from safe_mpc_amd import controller as Cn
+    from safe_mpc_amd.parser import Parameters
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N = 6, 6, [12, 256, 1], 6
+    ctrl = Cn.get_controller('receding', par, 4, device_state=True)
+    sv, L = ctrl.ocp_solver, ctrl.ocp_solver.L
+    x = torch.zeros((4, 12), dtype=torch.float64, device='cuda')
+    ptr = lambda t: t.data_ptr()
+    pp = sv._policy_params(ctrl.policy_kind, True)
+    full = [ptr(ctrl.x_guess), ptr(ctrl.u_guess), ptr(ctrl.x_temp), ptr(ctrl.u_temp), ptr(ctrl.p), ptr(ctrl.x_viable), ptr(ctrl.fails),
+            ptr(ctrl.current_step), ptr(ctrl.r), ptr(ctrl.last_status), ptr(ctrl.qp_iter)]
+    call = lambda pp_, st_, step=None, uo=None: L.smpc_policy_step(sv.h, 4, C.byref(pp_), C.byref(st_), ptr(x), step, uo, ptr(ctrl._u_out),
+                                                                   ptr(ctrl._abort_out), ptr(ctrl._any_abort))
+    no_r = list(full); no_r[8] = None
+    assert call(pp, _lib.PolicyState(*no_r)) < 0 and b'without r' in L.smpc_last_error(sv.h)
+    no_guess = list(full); no_guess[0] = None
+    assert call(pp, _lib.PolicyState(*no_guess)) < 0 and b'incomplete' in L.smpc_last_error(sv.h)
+    bad = sv._policy_params(17, True)
+    assert call(bad, _lib.PolicyState(*full)) < 0 and b'unknown policy' in L.smpc_last_error(sv.h)
+    mask = torch.ones(4, dtype=torch.bool, device='cuda')
+    assert call(pp, _lib.PolicyState(*full), step=ptr(mask), uo=None) < 0 and b'u_other' in L.smpc_last_error(sv.h)
+    rr = sv._policy_params(4, True)                          # RealReceding without its stage bounds
+    assert call(rr, _lib.PolicyState(*full)) < 0 and b'stage_lo' in L.smpc_last_error(sv.h)
+    assert L.smpc_loop_pre(sv.h, 4, 5, None, None, None, None, None) < 0
+    assert call(pp, _lib.PolicyState(*full)) == 0            # and the well-formed call still goes through
+    sv.sync()
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
