@@ -198,6 +198,17 @@ int ensure_mlp(smpc_handle* h, size_t M) {
     return SMPC_OK;
 }
 
+// list of live network rows (mode 3 of run_mlp) and its device-side length
+int ensure_nn_idx(smpc_handle* h, size_t M) {
+    if (M <= h->nn_idx_cap) return SMPC_OK;
+    int rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = dev_alloc(h, &h->d_nn_idx, M + 1))) return rc;
+    h->nn_idx_cap = M;
+    h->d_nn_cnt = h->d_nn_idx + M;
+    return SMPC_OK;
+}
+
 // forward (and optionally backward) pass of the network over M rows whose states are found through (mode, N) in x.
 // mode 3: the rows are the compacted list h->d_nn_idx of live nodes; their count is only known on the device (h->d_nn_cnt), so
 // the grids cover all M candidate rows and the blocks past the count return at once.
@@ -262,12 +273,7 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
         const int M = mode == 1 ? B : B * N;
         int rc;
         if (mode == 3) {
-            if ((size_t)M > h->nn_idx_cap) {
-                HIPCHK(h, hipStreamSynchronize(s));
-                if ((rc = dev_alloc(h, &h->d_nn_idx, (size_t)M + 1))) return rc;
-                h->nn_idx_cap = (size_t)M;
-                h->d_nn_cnt = h->d_nn_idx + M;
-            }
+            if ((rc = ensure_nn_idx(h, (size_t)M))) return rc;
             HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
             hipLaunchKernelGGL(k_nn_compact, dim3((M + 255) / 256), dim3(256), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
         }
@@ -369,7 +375,7 @@ int upload_check_bounds(smpc_handle* h, const double* x_min, const double* x_max
 // state test (+ safe-set test if d_nn) of B trajectories of n_nodes nodes on the device, against the uploaded check bounds;
 // collision rows on the leading coll_nodes nodes only
 int check_nodes_dev(smpc_handle* h, int B, int n_nodes, const double* d_x, double tol_x, int coll_nodes, double alpha,
-                    double tol_safe, int32_t* d_ok, int32_t* d_nn) {
+                    double tol_safe, int32_t* d_ok, int32_t* d_nn, bool nn_listed = false) {
     const int nq = h->desc.nq, nx = 2 * nq;
     hipStream_t s = h->stream;
     const size_t M = (size_t)B * n_nodes;
@@ -387,13 +393,17 @@ int check_nodes_dev(smpc_handle* h, int B, int n_nodes, const double* d_x, doubl
     HIPCHK(h, hipGetLastError());
     if (d_nn) {
         int rc;
-        DISPATCH_NQ(h, (run_mlp<NQ_>(h, (int)M, 0, 0, d_x, false)));
+        // nn_listed: only the nodes in h->d_nn_idx (length on the device, h->d_nn_cnt) are evaluated; their verdicts land at the
+        // nodes' own positions of d_nn, the rest of d_nn is left as it is
+        DISPATCH_NQ(h, (run_mlp<NQ_>(h, (int)M, nn_listed ? 3 : 0, 0, d_x, false)));
         if (rc) return rc;
         const dim3 g2((unsigned)((M + 255) / 256)), b2(256);
+        const int32_t* li = nn_listed ? h->d_nn_idx : nullptr;
+        const int32_t* lc = nn_listed ? h->d_nn_cnt : nullptr;
         switch (nq) {
-        case 5: hipLaunchKernelGGL((k_check_nn<5>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
-        case 6: hipLaunchKernelGGL((k_check_nn<6>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
-        default: hipLaunchKernelGGL((k_check_nn<7>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn); break;
+        case 5: hipLaunchKernelGGL((k_check_nn<5>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn, li, lc); break;
+        case 6: hipLaunchKernelGGL((k_check_nn<6>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn, li, lc); break;
+        default: hipLaunchKernelGGL((k_check_nn<7>), g2, b2, 0, s, h->d_desc, (int)M, d_x, alpha, tol_safe, h->d_y, d_nn, li, lc); break;
         }
         HIPCHK(h, hipGetLastError());
     }
@@ -1025,7 +1035,16 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
     if (kind != SMPC_POLICY_NAIVE) {
         // checkStateConstraints(x_temp) (+ checkSafeConstraints(x_temp) on every node for the receding policies)
         const int coll = par->collision_first_node ? 1 : N + 1;
-        if ((rc = check_nodes_dev(h, B, N + 1, st->x_temp, par->tol_x, coll, par->alpha, par->tol_safe, d_ok, receding ? d_safe : nullptr)))
+        if (receding) {
+            // the safe-set test is only ever read at nodes r + 2 .. N of the stepping instances (k_policy_post): list them
+            const size_t M = (size_t)B * (N + 1);
+            if ((rc = ensure_nn_idx(h, M))) return rc;
+            HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_policy_safe_list, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, B, N, par->abort_flag, stepping, st->r,
+                               h->d_nn_idx, h->d_nn_cnt);
+        }
+        if ((rc = check_nodes_dev(h, B, N + 1, st->x_temp, par->tol_x, coll, par->alpha, par->tol_safe, d_ok, receding ? d_safe : nullptr,
+                                  receding)))
             return rc;
     }
     hipLaunchKernelGGL(k_policy_post, dim3((B + 255) / 256), dim3(256), 0, s, B, N, nx, kind, par->abort_flag, stepping, st->status,

@@ -129,10 +129,13 @@ __global__ void k_check_nodes(const smpc_problem_desc* __restrict__ D, int B, in
 // safe-set acceptance test (safe_set.py:61-68): g(x, alpha) within [-tol, 1e6 + tol]
 template <int NQ>
 __global__ void k_check_nn(const smpc_problem_desc* __restrict__ D, int M, const double* __restrict__ x, double alpha,
-                           double tol_safe, const float* __restrict__ y, int32_t* __restrict__ nn_ok) {
+                           double tol_safe, const float* __restrict__ y, int32_t* __restrict__ nn_ok,
+                           const int32_t* __restrict__ idx, const int32_t* __restrict__ m_live) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const double* xk = x + (size_t)m * 2 * NQ;
+    if (m_live && m >= *m_live) return;
+    const long node = idx ? idx[m] : m;        // (compacted list of nodes, kernels_mlp.hpp mode 3; verdicts land at the nodes)
+    const double* xk = x + (size_t)node * 2 * NQ;
     const int nd = D->nn_dof;
     double vn2 = 0.0;
 #pragma unroll
@@ -141,7 +144,7 @@ __global__ void k_check_nn(const smpc_problem_desc* __restrict__ D, int M, const
         vn2 += v * v;
     }
     const double g = (double)y[m] * (100.0 - alpha) / 100.0 - sqrt(vn2);
-    nn_ok[m] = (g >= -tol_safe) && (g <= 1e6 + tol_safe);
+    nn_ok[node] = (g >= -tol_safe) && (g <= 1e6 + tol_safe);
 }
 
 // NaiveController.step's bookkeeping (controller.py:279-283): fails = status == 0 ? 0 : fails + 1; accept = fails == 0

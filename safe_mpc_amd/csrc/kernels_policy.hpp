@@ -35,6 +35,27 @@ __global__ void k_policy_pre(int B, int N, int nx, int kind, const uint8_t* __re
     }
 }
 
+// The receding policies move r to the last safe node of the NEW trajectory, looking at nodes r + 2 .. N only
+// (controller.py:491-494) -- in steady state one or two nodes per instance.  This builds the list of those (instance, node) pairs
+// so that the network is evaluated there and nowhere else.  r is taken after this step's decrement / abort reset, exactly as
+// k_policy_post will see it.  One thread per (instance, node).
+__global__ void k_policy_safe_list(int B, int N, int abort_flag, const uint8_t* __restrict__ stepping, const int64_t* __restrict__ r_all,
+                                   int32_t* __restrict__ idx, int32_t* __restrict__ count) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * (N + 1)) return;
+    const long b = t / (N + 1);
+    const int k = (int)(t - b * (N + 1));
+    if (stepping && !stepping[b]) return;
+    int64_t r = r_all[b];
+    if (abort_flag) {
+        r -= 1;
+        if (r == 0) r += N;
+    } else {
+        r -= r > 0 ? 1 : 0;
+    }
+    if (k >= r + 2) idx[atomicAdd(count, 1)] = (int32_t)t;
+}
+
 // What follows the solve in <Controller>.step, per instance:
 //   NAIVE        controller.py:274-284   fails = status == 0 ? 0 : fails + 1
 //   STATE_CHECK  controller.py:651-661   the same with ok = status == 0 and checkStateConstraints(x_temp)
