@@ -568,6 +568,33 @@ def test_policy_entry_points_reject_misuse():
     sv.sync()
 
 
+@pytest.mark.parametrize('controller', ['st', 'constraint_everywhere'])
+def test_engine_against_independent_dense_qp_solver_at_full_horizon(controller):
+    """The engine's RTI step at the bench's size (Z1, N = 30) against tests/qp_ref.py -- a condensed dense QP solved by a plain
+    log-barrier Newton method with numpy.linalg: no Riccati recursion, no Mehrotra corrector, different variables.  The QP data
+    come from the oracle's linearisation (which the engine matches to 1e-14, test_eval_nodes_parity); what is pinned here is
+    the QP solution itself, independently of the oracle's interior-point method."""
+    from qp_ref import condense, solve_condensed
+    par, prob, net = make_problem(controller, 'ext', N=30)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    x0 = sample_instances(prob, 4, seed=5, vel_scale=0.2)
+    xg, ug, p = constant_guess(prob, x0)
+    rng = np.random.default_rng(1)
+    ug += rng.uniform(-2, 2, ug.shape)
+    xg[:, 1:] += 0.01 * rng.standard_normal(xg[:, 1:].shape)
+    xa, ua, sa, ia = s.solve(x0 + 0.002, xg, ug, p)
+    assert (sa == 0).sum() >= 3
+    for b in range(4):
+        if sa[b] != 0:
+            continue
+        cq = condense(o.build_qp(x0[b] + 0.002, xg[b], ug[b], p[b]), 30, 6, par.dt)
+        v, _, _, nit = solve_condensed(cq)
+        assert nit < 150
+        du = (ua[b] - ug[b]).reshape(-1)
+        assert np.abs(du - v).max() < 2e-6 * (1.0 + np.abs(v).max()), (controller, b, np.abs(du - v).max())
+        assert np.allclose(xa[b, 30] - xg[b, 30], cq['Phi'][30] @ v + cq['c'][30], atol=1e-6)
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal

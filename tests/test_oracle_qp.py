@@ -15,7 +15,7 @@ def _setup(controller, N, cost='ext'):
 
 
 @pytest.mark.parametrize('controller,N', [('naive', 8), ('zerovel', 8), ('st', 6), ('htwa', 6),
-                                          ('constraint_everywhere', 6)])
+                                          ('constraint_everywhere', 6), ('st', 30), ('constraint_everywhere', 30)])
 def test_ipm_matches_independent_dense_solver(controller, N):
     par, prob, net, o = _setup(controller, N)
     x0 = sample_instances(prob, 3, seed=1, vel_scale=0.2)
