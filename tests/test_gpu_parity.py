@@ -595,6 +595,27 @@ def test_engine_against_independent_dense_qp_solver_at_full_horizon(controller):
         assert np.allclose(xa[b, 30] - xg[b, 30], cq['Phi'][30] @ v + cq['c'][30], atol=1e-6)
 
 
+def test_engine_against_independent_dense_qp_solver_c4():
+    """The same for BASELINE config 4 (7-DoF, N = 40, safe-set row on every node)."""
+    from conftest import make_problem_fr7
+    from qp_ref import condense, solve_condensed
+    par, prob, net = make_problem_fr7(N=40)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    x0 = sample_instances(prob, 3, seed=2, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0, ee_ref=prob.ee_ref)
+    rng = np.random.default_rng(0)
+    ug += rng.uniform(-1, 1, ug.shape)
+    xg[:, 1:] += 0.005 * rng.standard_normal(xg[:, 1:].shape)
+    xa, ua, sa, ia = s.solve(x0 + 0.001, xg, ug, p)
+    assert (sa == 0).all()
+    for b in range(3):
+        cq = condense(o.build_qp(x0[b] + 0.001, xg[b], ug[b], p[b]), 40, 7, par.dt)
+        v, _, _, nit = solve_condensed(cq)
+        du = (ua[b] - ug[b]).reshape(-1)
+        # (fp32 network in the engine, fp64 restatement in the oracle's QP data: the row differs by ~1e-7 relative)
+        assert np.abs(du - v).max() < 1e-4 * (1.0 + np.abs(v).max()), (b, np.abs(du - v).max())
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal

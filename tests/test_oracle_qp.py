@@ -40,6 +40,26 @@ def test_ipm_matches_independent_dense_solver(controller, N):
     assert (st == 0).sum() >= 2
 
 
+def test_ipm_matches_independent_dense_solver_c4():
+    """BASELINE config 4 (7-DoF, N = 40, safe-set row on every node): the oracle's QP solution against the dense solver."""
+    from conftest import make_problem_fr7
+    par, prob, net = make_problem_fr7(N=40)
+    o = Oracle(prob, (net.weights, net.biases))
+    x0 = sample_instances(prob, 3, seed=2, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x0, ee_ref=prob.ee_ref)
+    rng = np.random.default_rng(0)
+    ug += rng.uniform(-1, 1, ug.shape)
+    xg[:, 1:] += 0.005 * rng.standard_normal(xg[:, 1:].shape)
+    xo, uo, st, it = o.solve_batch(x0 + 0.001, xg, ug, p)
+    assert (st == 0).all()
+    for b in range(3):
+        cq = condense(o.build_qp(x0[b] + 0.001, xg[b], ug[b], p[b]), 40, 7, par.dt)
+        v, _, _, nit = solve_condensed(cq)
+        assert nit < 150
+        du = (uo[b] - ug[b]).reshape(-1)
+        assert np.abs(du - v).max() < 2e-6 * (1.0 + np.abs(v).max())
+
+
 def test_rti_step_structure():
     """x_out[0] = x0, the output satisfies the double integrator exactly, status 0, few iterations."""
     par, prob, net, o = _setup('st', 30)
