@@ -616,6 +616,62 @@ def test_engine_against_independent_dense_qp_solver_c4():
         assert np.abs(du - v).max() < 1e-4 * (1.0 + np.abs(v).max()), (b, np.abs(du - v).max())
 
 
+@pytest.mark.parametrize('nq', [6, 7])
+def test_engine_jacobians_by_central_differences_of_its_own_values(nq):
+    """Independent of the oracle: every Jacobian the engine's linearisation kernels produce (closed-form RNEA derivatives,
+    tangents through the clamped segment-distance expressions, the network's input gradient, the cost gradient) against
+    central differences of the engine's OWN values at perturbed states / controls."""
+    if nq == 6:
+        par, prob, net = make_problem('constraint_everywhere', 'ext', N=4)
+    else:
+        from conftest import make_problem_fr7
+        par, prob, net = make_problem_fr7(N=4)
+    s = _solver(prob, net)
+    B, N, nx = 6, 4, 2 * nq
+    x0 = sample_instances(prob, B, seed=4, vel_scale=0.4)
+    xg, ug, p = constant_guess(prob, x0) if nq == 6 else constant_guess(prob, x0, ee_ref=prob.ee_ref)
+    rng = np.random.default_rng(2)
+    xg = xg + 0.05 * rng.standard_normal(xg.shape)
+    ug = ug + rng.uniform(-3, 3, ug.shape)
+    base = s.eval_nodes(xg, ug, p)
+    nr = prob.desc.n_rows
+    h = 1e-6
+
+    def shifted(arr, idx, sign, step=None):
+        a = arr.copy()
+        a[..., idx] += sign * (h if step is None else step)
+        return a
+    # d tau / dq, d tau / dqd, rows, network, cost: central differences in every state coordinate
+    d_tau = np.zeros((B, N + 1, nq, nx)); d_row = np.zeros((B, N + 1, nr, nx)); d_nn = np.zeros((B, N + 1, nx)); d_cost = np.zeros((B, N + 1, nq))
+    for i in range(nx):
+        ep, em = s.eval_nodes(shifted(xg, i, +1), ug, p), s.eval_nodes(shifted(xg, i, -1), ug, p)
+        d_tau[..., i] = (ep['tau'][..., :nq] - em['tau'][..., :nq]) / (2 * h)
+        d_row[..., i] = (ep['row_val'][..., :nr] - em['row_val'][..., :nr]) / (2 * h)
+        # (the network runs in fp32: its value resolves a difference only over a much wider step)
+        hn = 4e-3
+        d_nn[..., i] = (s.eval_nodes(shifted(xg, i, +1, hn), ug, p)['nn_val'] - s.eval_nodes(shifted(xg, i, -1, hn), ug, p)['nn_val']) / (2 * hn)
+        if i < nq:
+            # cost value is not exported; its gradient is Q d|ee - ref|^2 / dq = 2 Q J^T (ee - ref): differentiate ee instead
+            de = (ep['ee'] - em['ee']) / (2 * h)                                     # [B, N+1, 3] = column i of J
+            d_cost[..., i] = 2.0 * prob.desc.Q * (de * (base['ee'] - p[:, :, :3])).sum(-1)
+    M_fd = np.zeros((B, N + 1, nq, nq))
+    for i in range(nq):
+        ep, em = s.eval_nodes(xg, shifted(ug, i, +1), p), s.eval_nodes(xg, shifted(ug, i, -1), p)
+        M_fd[..., i] = (ep['tau'][..., :nq] - em['tau'][..., :nq]) / (2 * h)
+    run = slice(0, N)                                                                # the torque row lives on nodes 0 .. N-1
+    J = lambda f: base[f][:, run, :nq * nq].reshape(B, N, nq, nq)
+    scale = 1.0 + np.abs(base['tau'][:, run, :nq]).max()
+    assert np.abs(J('dtau_dq') - d_tau[:, run, :, :nq]).max() < 2e-5 * scale
+    assert np.abs(J('dtau_dv') - d_tau[:, run, :, nq:]).max() < 2e-5 * scale
+    assert np.abs(J('M') - M_fd[:, run]).max() < 2e-5 * scale
+    rg = base['row_grad'][..., :nr * nq].reshape(B, N + 1, nr, nq)
+    assert np.abs(rg - d_row[..., :nq]).max() < 1e-5 * (1.0 + np.abs(rg).max()) and np.abs(d_row[..., nq:]).max() < 1e-8
+    assert np.abs(base['cost_grad_q'][..., :nq] - d_cost).max() < 1e-5 * (1.0 + np.abs(d_cost).max())
+    ng = base['nn_grad'][:, 1:, :]                                                   # (fp32 network: differences of fp32 values)
+    g_fd = d_nn[:, 1:]
+    assert np.abs(np.concatenate([ng[..., :nq], ng[..., nq:2 * nq]], -1) - g_fd).max() < 2e-2 * (1.0 + np.abs(g_fd).max())
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
