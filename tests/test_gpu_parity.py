@@ -672,6 +672,63 @@ def test_engine_jacobians_by_central_differences_of_its_own_values(nq):
     assert np.abs(np.concatenate([ng[..., :nq], ng[..., nq:2 * nq]], -1) - g_fd).max() < 2e-2 * (1.0 + np.abs(g_fd).max())
 
 
+def test_engine_inverse_dynamics_known_answer_double_pendulum():
+    """First principles, no oracle: a planar 2R arm (both axes y, point masses at the link tips) embedded as the first two joints
+    of a 5-joint chain whose other links are massless.  The engine's torque row, mass matrix and Jacobians against the textbook
+    M(q) qdd + C(q, qd) + g(q) and its derivatives."""
+    G = 9.80665
+    par, prob, net = make_problem('naive', 'ext', N=3, nq=5)
+    m1, m2, l1, l2 = 0.9, 0.6, 0.5, 0.4
+    for i in range(5):
+        J = prob.desc.joints[i]
+        J.R0[:] = np.eye(3).reshape(-1).tolist()
+        J.p0[:] = [0.0, 0.0, 0.0]
+        J.axis[:] = [0.0, 1.0, 0.0]
+        J.mass = 0.0
+        J.com[:] = [0.0, 0.0, 0.0]
+        J.inertia[:] = [0.0] * 6
+        J.tau_max = 1e3
+    for i, (m, l, p0) in enumerate([(m1, l1, [0, 0, 0]), (m2, l2, [l1, 0, 0])]):
+        J = prob.desc.joints[i]
+        J.p0[:] = [float(v) for v in p0]
+        J.mass = m
+        J.com[:] = [l, 0.0, 0.0]
+    prob.desc.gravity[:] = [0.0, 0.0, -G]
+    s = _solver(prob, None)
+    rng = np.random.default_rng(3)
+    B, N = 8, 3
+    xg = rng.uniform(-2, 2, (B, N + 1, 10))
+    ug = rng.uniform(-3, 3, (B, N, 5))
+    p = np.zeros((B, N + 1, 5)); p[:, :, 4] = 1.0
+    ev = s.eval_nodes(xg, ug, p)
+
+    def textbook(q, qd, qdd):
+        c2, s2 = np.cos(q[1]), np.sin(q[1])
+        M = np.array([[m1 * l1 ** 2 + m2 * (l1 ** 2 + l2 ** 2 + 2 * l1 * l2 * c2), m2 * (l2 ** 2 + l1 * l2 * c2)],
+                      [m2 * (l2 ** 2 + l1 * l2 * c2), m2 * l2 ** 2]])
+        h = m2 * l1 * l2 * s2
+        Cv = np.array([-h * (2 * qd[0] * qd[1] + qd[1] ** 2), h * qd[0] ** 2])
+        g = -G * np.array([(m1 + m2) * l1 * np.cos(q[0]) + m2 * l2 * np.cos(q[0] + q[1]), m2 * l2 * np.cos(q[0] + q[1])])
+        return M, Cv, g, M @ qdd + Cv + g
+    for b in range(B):
+        for k in range(N):
+            q, qd, qdd = xg[b, k, :2], xg[b, k, 5:7], ug[b, k, :2]
+            M, Cv, g, tau = textbook(q, qd, qdd)
+            assert np.allclose(ev['tau'][b, k, :2], tau, atol=1e-11) and np.allclose(ev['tau'][b, k, 2:5], 0.0, atol=1e-12)
+            Me = ev['M'][b, k, :25].reshape(5, 5)
+            assert np.allclose(Me[:2, :2], M, atol=1e-11) and np.allclose(Me[2:], 0.0, atol=1e-12)
+            # d tau / d qd of the textbook Coriolis terms
+            h = m2 * l1 * l2 * np.sin(q[1])
+            dv = np.array([[-2 * h * qd[1], -2 * h * (qd[0] + qd[1])], [2 * h * qd[0], 0.0]])
+            assert np.allclose(ev['dtau_dv'][b, k, :25].reshape(5, 5)[:2, :2], dv, atol=1e-11)
+            # d tau / dq by differencing the textbook expression
+            dq = np.zeros((2, 2))
+            for j in range(2):
+                e = np.zeros(2); e[j] = 1e-6
+                dq[:, j] = (textbook(q + e, qd, qdd)[3] - textbook(q - e, qd, qdd)[3]) / 2e-6
+            assert np.allclose(ev['dtau_dq'][b, k, :25].reshape(5, 5)[:2, :2], dq, atol=1e-7)
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
