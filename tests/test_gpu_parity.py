@@ -729,6 +729,36 @@ def test_engine_inverse_dynamics_known_answer_double_pendulum():
             assert np.allclose(ev['dtau_dq'][b, k, :25].reshape(5, 5)[:2, :2], dq, atol=1e-7)
 
 
+def test_engine_safe_set_row_against_torch_autograd():
+    """Oracle-free pin of the MFMA network kernels and the chain rule back to the state: the engine's safe-set row value and
+    gradient at every node against safe_set.py:82-94 restated in torch (float64 copy of the network, autograd)."""
+    import torch
+    par, prob, net = make_problem('constraint_everywhere', 'ext', N=5)
+    s = _solver(prob, net)
+    rng = np.random.default_rng(7)
+    B, N = 12, 5
+    xg = np.concatenate([rng.uniform(prob.lbx[:6], prob.ubx[:6], (B, N + 1, 6)), rng.uniform(-1, 1, (B, N + 1, 6))], -1)
+    ug = np.zeros((B, N, 6))
+    p = np.zeros((B, N + 1, 5)); p[:, :, :3], p[:, :, 3], p[:, :, 4] = prob.ee_ref, par.alpha, 1.0
+    ev = s.eval_nodes(xg, ug, p)
+    net64 = net.model.double()
+    try:
+        mean, std = torch.tensor(net.mean), torch.tensor(net.std)
+        worst_v = worst_g = 0.0
+        for b in range(B):
+            for k in range(1, N + 1):
+                xt = torch.tensor(xg[b, k], dtype=torch.float64, requires_grad=True)
+                xc = xt + torch.nn.functional.one_hot(torch.tensor(6), 12).double() * par.eps
+                vn = torch.linalg.norm(xc[6:])
+                g = net64(torch.cat([(xc[:6] - mean) / std, xc[6:] / vn]))[0] * (100 - par.alpha) / 100 - vn
+                g.backward()
+                worst_v = max(worst_v, abs(ev['nn_val'][b, k] - g.item()) / (1.0 + abs(g.item())))
+                worst_g = max(worst_g, np.abs(ev['nn_grad'][b, k, :12] - xt.grad.numpy()).max() / (1.0 + np.abs(xt.grad.numpy()).max()))
+        assert worst_v < 2e-5 and worst_g < 5e-4, (worst_v, worst_g)
+    finally:
+        net.model.float()
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
