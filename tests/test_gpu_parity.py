@@ -759,6 +759,45 @@ def test_engine_safe_set_row_against_torch_autograd():
         net.model.float()
 
 
+def test_engine_collision_rows_against_brute_force_geometry():
+    """Oracle-free: the engine's collision-row values against the geometry done by hand -- forward kinematics as a product of
+    the URDF's transforms in numpy, then the squared distance between the two capsule axes by brute force over a fine grid
+    (the reference's expression, utils.py:94-113, is that distance up to its 1e-5 regulariser, never below it)."""
+    from safe_mpc_amd.urdf import _axis_angle
+    par, prob, net = make_problem('naive', 'ext', N=2)
+    s = _solver(prob, None)
+    rng = np.random.default_rng(5)
+    B, N = 10, 2
+    q = rng.uniform(prob.lbx[:6], prob.ubx[:6], (B, 6))
+    xg = np.tile(np.concatenate([q, np.zeros((B, 6))], 1)[:, None, :], (1, N + 1, 1))
+    ev = s.eval_nodes(xg, np.zeros((B, N, 6)), np.zeros((B, N + 1, 5)))
+
+    def world_point(qb, pt):
+        R, pw = np.eye(3), np.zeros(3)
+        for i, j in enumerate(prob.chain.joints[:pt.link + 1]):
+            pw = pw + R @ j.p0
+            R = R @ j.R0 @ _axis_angle(j.axis, qb[i])
+        return pw + R @ np.array(pt.local)
+    t = np.linspace(0, 1, 300)
+    checked = 0
+    for b in range(B):
+        for r in range(prob.desc.n_rows):
+            row = prob.desc.rows[r]
+            if row.kind not in (0, 1):                       # SEG_FIXEDSEG / SEG_SEG: the capsule pairs of config.yaml:205-216
+                continue
+            A, Bp = world_point(q[b], prob.desc.points[row.pa]), world_point(q[b], prob.desc.points[row.pb])
+            if row.kind == 0:
+                Cc, Dd = np.array(row.C), np.array(row.D)
+            else:
+                Cc, Dd = world_point(q[b], prob.desc.points[row.pc]), world_point(q[b], prob.desc.points[row.pd])
+            P = A[None] + t[:, None] * (Bp - A)[None]
+            Qp = Cc[None] + t[:, None] * (Dd - Cc)[None]
+            bf = np.min(np.sum((P[:, None, :] - Qp[None, :, :]) ** 2, axis=-1))
+            assert bf - 1e-4 <= ev['row_val'][b, 1, r] <= bf + 5e-3, (b, r, bf, ev['row_val'][b, 1, r])
+            checked += 1
+    assert checked >= 30
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
