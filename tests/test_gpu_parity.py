@@ -643,6 +643,7 @@ def test_engine_jacobians_by_central_differences_of_its_own_values(nq):
         return a
     # d tau / dq, d tau / dqd, rows, network, cost: central differences in every state coordinate
     d_tau = np.zeros((B, N + 1, nq, nx)); d_row = np.zeros((B, N + 1, nr, nx)); d_nn = np.zeros((B, N + 1, nx)); d_cost = np.zeros((B, N + 1, nq))
+    d_grad = np.zeros((B, N + 1, nq, nq))
     for i in range(nx):
         ep, em = s.eval_nodes(shifted(xg, i, +1), ug, p), s.eval_nodes(shifted(xg, i, -1), ug, p)
         d_tau[..., i] = (ep['tau'][..., :nq] - em['tau'][..., :nq]) / (2 * h)
@@ -654,6 +655,7 @@ def test_engine_jacobians_by_central_differences_of_its_own_values(nq):
             # cost value is not exported; its gradient is Q d|ee - ref|^2 / dq = 2 Q J^T (ee - ref): differentiate ee instead
             de = (ep['ee'] - em['ee']) / (2 * h)                                     # [B, N+1, 3] = column i of J
             d_cost[..., i] = 2.0 * prob.desc.Q * (de * (base['ee'] - p[:, :, :3])).sum(-1)
+            d_grad[..., i] = (ep['cost_grad_q'][..., :nq] - em['cost_grad_q'][..., :nq]) / (2 * h)
     M_fd = np.zeros((B, N + 1, nq, nq))
     for i in range(nq):
         ep, em = s.eval_nodes(xg, shifted(ug, i, +1), p), s.eval_nodes(xg, shifted(ug, i, -1), p)
@@ -667,6 +669,9 @@ def test_engine_jacobians_by_central_differences_of_its_own_values(nq):
     rg = base['row_grad'][..., :nr * nq].reshape(B, N + 1, nr, nq)
     assert np.abs(rg - d_row[..., :nq]).max() < 1e-5 * (1.0 + np.abs(rg).max()) and np.abs(d_row[..., nq:]).max() < 1e-8
     assert np.abs(base['cost_grad_q'][..., :nq] - d_cost).max() < 1e-5 * (1.0 + np.abs(d_cost).max())
+    if prob.desc.hessian == 1:                                                       # SMPC_HESS_EXACT: the true second derivative
+        Hq = base['cost_hess_qq'][..., :nq * nq].reshape(B, N + 1, nq, nq)
+        assert np.abs(Hq - d_grad).max() < 1e-5 * (1.0 + np.abs(Hq).max())
     ng = base['nn_grad'][:, 1:, :]                                                   # (fp32 network: differences of fp32 values)
     g_fd = d_nn[:, 1:]
     assert np.abs(np.concatenate([ng[..., :nq], ng[..., nq:2 * nq]], -1) - g_fd).max() < 2e-2 * (1.0 + np.abs(g_fd).max())
