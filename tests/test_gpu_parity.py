@@ -803,6 +803,26 @@ def test_engine_collision_rows_against_brute_force_geometry():
     assert checked >= 30
 
 
+def test_engine_plant_step_is_consistent_with_its_inverse_dynamics():
+    """AdamModel.integrate (env_model.py:192-206) restated through the engine's own pieces: the acceleration the plant step
+    applies, pushed back through the torque row, must give the clipped commanded torque; then the double integrator."""
+    par, prob, net = make_problem('naive', 'ext', N=1)
+    s = _solver(prob, None)
+    rng = np.random.default_rng(11)
+    B = 32
+    x = np.concatenate([rng.uniform(prob.lbx[:6], prob.ubx[:6], (B, 6)), rng.uniform(-1, 1, (B, 6))], 1)
+    u = rng.uniform(-1, 1, (B, 6)) * np.where(rng.random((B, 1)) < 0.5, 4.0, 600.0)       # half of them saturate the torques
+    noise = rng.normal(scale=0.3, size=(B, 6))
+    xn, acc = s.plant_step(x, u, None, noise)
+    tau_of = lambda a: s.eval_nodes(np.stack([x, x], 1), a[:, None, :], np.zeros((B, 2, 5)))['tau'][:, 0, :6]
+    tau_cmd = np.clip(tau_of(u) + noise, -prob.tau_max, prob.tau_max)
+    assert (np.abs(tau_of(u) + noise) > prob.tau_max).any()                                 # the clip was exercised
+    assert np.abs(tau_of(acc) - tau_cmd).max() < 1e-9 * (1.0 + np.abs(tau_cmd).max())
+    dt = par.dt
+    assert np.allclose(xn[:, :6], x[:, :6] + dt * x[:, 6:] + 0.5 * dt * dt * acc, atol=1e-13)
+    assert np.allclose(xn[:, 6:], x[:, 6:] + dt * acc, atol=1e-13)
+
+
 def test_generate_guess_merit_backtracking_on_engine():
     """guess generation = SQP with merit backtracking (parser.py:115-117,139; guess_acados.py:98-158) on the
     engine: accepted guesses satisfy checkGuess, the l1 merit never increases along accepted steps, and the hard-terminal
