@@ -1,6 +1,10 @@
 """Array backend of the policy layer: the same controller / closed-loop code runs on numpy arrays (host path of the engine,
 CPU tests with the oracle double) or on ROCm torch tensors (device path: every per-instance state array of the policy
 automata lives in HBM and no step of the loop copies it to the host).  Only the handful of operations the policies use.
+
+On the device the per-step automata themselves run as engine kernels (smpc_policy_step / smpc_loop_*, kernels_policy.hpp);
+what goes through TorchOps there is the set-up (initialize, setGuess, checkGuess), the abort-event bookkeeping and the
+result assembly -- and any step() of a controller driven by a solver object that does not offer those kernels.
 """
 from __future__ import annotations
 
@@ -78,12 +82,6 @@ class NumpyOps:
     def clip_max(self, a, hi):
         return np.minimum(a, hi)
 
-    def isnan_any_tail(self, a):
-        return np.isnan(a.reshape(a.shape[0], -1)).any(1)
-
-    def nan_to_num(self, a):
-        return np.nan_to_num(a)
-
     def host(self, a):
         return np.asarray(a)
 
@@ -157,12 +155,6 @@ class TorchOps:
 
     def clip_max(self, a, hi):
         return self.t.clamp(a, max=hi)
-
-    def isnan_any_tail(self, a):
-        return self.t.isnan(a.reshape(a.shape[0], -1)).any(dim=1)
-
-    def nan_to_num(self, a):
-        return self.t.nan_to_num(a, nan=0.0)
 
     def host(self, a):
         return a.detach().cpu().numpy()
