@@ -217,7 +217,7 @@ class NaiveController(AbstractController):
 
     def step(self, x):
         """controller.py:274-284"""
-        if self.xp.on_device:
+        if self.xp.on_device and hasattr(self.ocp_solver, 'policy_step'):
             return self.step_on_device(x)
         self.guessCorrection()
         status = self.solve(x)
@@ -248,7 +248,7 @@ class STWAController(STController):
 
     def step(self, x):
         """controller.py:375-388"""
-        if self.xp.on_device:
+        if self.xp.on_device and hasattr(self.ocp_solver, 'policy_step'):
             return self.step_on_device(x)
         xp = self.xp
         self.guessCorrection()
@@ -316,7 +316,7 @@ class RecedingController(STWAController):
 
     def step(self, x):
         """controller.py:448-498"""
-        if self.xp.on_device:
+        if self.xp.on_device and hasattr(self.ocp_solver, 'policy_step'):
             return self.step_on_device(x)
         self.guessCorrection()
         self._set_flags()
@@ -340,7 +340,7 @@ class RealReceding(RecedingController):
             self._stage_hi = xp.asarray(np.vstack([np.tile(self.problem.x_max, (self.N, 1)), self.problem.ubx_e[None, :]]), xp.f64)
 
     def step(self, x):
-        if self.xp.on_device:
+        if self.xp.on_device and hasattr(self.ocp_solver, 'policy_step'):
             return self.step_on_device(x)
         xp, pr, N = self.xp, self.problem, self.N
         # other nodes: the model bounds (:534-536); the terminal node keeps lbx_e / ubx_e
@@ -367,7 +367,7 @@ class ControllerSafeSetEverywhere(STController):
 
     def step(self, x):
         """controller.py:651-661"""
-        if self.xp.on_device:
+        if self.xp.on_device and hasattr(self.ocp_solver, 'policy_step'):
             return self.step_on_device(x)
         xp = self.xp
         self.guessCorrection()
