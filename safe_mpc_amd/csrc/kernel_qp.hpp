@@ -973,8 +973,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             //  address space being lost)
             int o_xb = O_XB, o_xn = O_XB + NX;
             int o_wc = O_TD + CST_MAX, o_wn = O_TD + CST_MAX + NQ * KS;    // factor block of this stage / of the next one
-            dbl2 Cs[CST_PF], Ws[WST_PF], r0, r1, r2, r3;
-            double bi, wsoft;
+            dbl2 Cs[CST_PF], Ws[WST_PF];
+            // the rows of a stage (bounds, slacks, multipliers, c.z pair, (b_i, soft weight)) in TWO register sets: the loads of
+            // stage k + 1 go out at the top of stage k, a whole stage before their use.  (With one set they could only be
+            // issued after stage k's rows had been consumed, ~0.6 of a stage ahead -- under full load less than the memory
+            // latency, and the row phase of every forward stage stalled for the difference: 1.0 M of the 5.2 M clocks of a
+            // half-wave, profiles/r02_qp_phase_profile.txt.)
+            struct RSet { dbl2 r0, r1, r2, r3; double bi, wsoft; };
+            RSet RA, RB;
             // where piece j of this lane goes in the row-major LDS image (in doubles).  Piece 0 is always in the torque rows,
             // which the two layouts share; the collision / safe-set pieces move behind their rows' zero u columns.
             int cdst[CST_PF];
@@ -1012,20 +1018,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                 for (int j = 0; j < CST_PF; j++) Cs[j] = ldnt(s2 + min(hl + 32 * j, c_n2 - 1));
             };
-            auto load_r = [&](int k) {
+            auto load_r = [&](RSet& R, int k) {
                 const double* w = stage_ptr(k);
-                r0 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR0) + hr);
-                r1 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR1) + hr);
-                r2 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR2) + hr);
-                if (CORR) r3 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR3) + hr);
+                R.r0 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR0) + hr);
+                R.r1 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR1) + hr);
+                R.r2 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR2) + hr);
+                if (CORR) R.r3 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR3) + hr);
                 const dbl2 aux = ldnt_s(reinterpret_cast<const dbl2*>(w + Ly.oAUX) + hl_x);
-                bi = aux.x;
-                wsoft = aux.y;
+                R.bi = aux.x;
+                R.wsoft = aux.y;
             };
             if (hl < NX) sIMG[o_xb + hl] = dx0_reg;
             load_w(0);
             load_c(0);
-            load_r(0);
+            load_r(RA, 0);
             commit_w(sIMG + o_wc);
             load_w(N > 1 ? 1 : 0);
             lds_fence();
@@ -1034,8 +1040,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             // its wait INSIDE the loop body, where it then drains the prefetch queue on every stage.
             asm volatile("" : "+v"(o_wc), "+v"(o_wn), "+v"(o_xb), "+v"(o_xn));   // (reloaded here, not in the preheader)
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-#pragma unroll 1
-            for (int k = 0; k <= N; k++) {
+            auto stage_f = [&](int k, RSet& cur, RSet& nxt) {
                 if (CORR) asm volatile("; QPMARK F2_BEGIN"); else asm volatile("; QPMARK F1_BEGIN");
                 const bool last = (k == N);
                 const int kn = k < N ? k + 1 : N;          // past the end the loads repeat the end stage: they stay unconditional
@@ -1051,6 +1056,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     }
                 }
                 load_c(kn);
+                load_r(nxt, kn);
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
                     const double* wr_ = wc_ + hl_u * KS;
@@ -1072,7 +1078,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 if (!last && hl < NX) {
                     const int i = hl < NQ ? hl : hl - NQ;
                     const double u = sZU[i];
-                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi : xb[hl] + dt * u + bi;
+                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + cur.bi : xb[hl] + dt * u + cur.bi;
                 }
                 // rows: c.z for the trial point, directions, ratio test
                 {
@@ -1083,7 +1089,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                     for (int c = 0; c < NX; c++) a = fma(cr[NU + c], xb[c], a);
                     const double cz = hr < NX ? xb[hl_x] : a;
-                    const QpRow rs{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+                    const QpRow rs{cur.r0.x, cur.r0.y, cur.r1.x, cur.r1.y, cur.r2.x, cur.r2.y};
+                    const double wsoft = cur.wsoft;
                     const bool soft = soft_lane && wsoft >= 0.0;
                     double s1_ = 0.0, s2_ = 0.0;
                     if (!CORR) {
@@ -1095,14 +1102,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     } else {
                         // (both halves of the pair are read: a loaded-but-unread register would be handed out again while the
                         //  load is in flight, which costs a full vmcnt(0) at that point)
-                        const double cza = fma(0.0, r3.y, r3.x);
+                        const double cza = fma(0.0, cur.r3.y, cur.r3.x);
                         qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, cza, &rr, &s1_, &s2_, nullptr, nullptr);
                         stnt_s(cz, w + Ly.oR3 + 2 * hr + 1);
                         stnt_s(hz < NU ? sZU[hl_u] : xb[hl_px], w + Ly.oZN + hz);
                     }
                     S1 += row_live ? s1_ : 0.0;
                     S2 += row_live ? s2_ : 0.0;
-                    load_r(kn);
                 }
                 // next stage's factor block -> its LDS buffer; the one after that -> registers
                 commit_w(wn_);
@@ -1126,6 +1132,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 { const int t = o_wc; o_wc = o_wn; o_wn = t; }
                 QPT(CORR ? 11 : 7);
                 if (CORR) asm volatile("; QPMARK F2_END"); else asm volatile("; QPMARK F1_END");
+            };
+            {
+                int k = 0;
+#pragma unroll 1
+                for (; k + 1 <= N; k += 2) {
+                    stage_f(k, RA, RB);
+                    stage_f(k + 1, RB, RA);
+                }
+                if (k <= N) stage_f(k, RA, RB);
             }
             *rr_out = half_max(rr);
             *S1_out = half_sum(S1);
