@@ -55,8 +55,12 @@ constexpr double QP_ALPHA_MIN = 1e-12;
 constexpr double QP_ABSENT = 1e300;  // sentinel for a missing bound side inside the workspace
 
 constexpr int qp_even_c(int n) { return (n + 1) & ~1; }
+constexpr int qp_al8(int n) { return (n + 7) & ~7; }   // block sizes in the stage record: multiples of 64 bytes
 
-// Workspace of one stage, in doubles; every block starts on a 16-byte boundary.
+// Workspace of one stage, in doubles.  Every block starts on a 64-byte boundary and the record on a 128-byte one: stores are
+// what this kernel's memory stream pays most for (scripts/mem_pipeline_probe.hip, profiles/r03_mem_pipeline_probe_stores.txt:
+// a store costs 2-3 x its bytes in read-equivalents, an 8-byte store 16 bytes away from its neighbour a read-modify-write
+// of the sectors it touches), so everything a sweep writes is contiguous, sector-aligned and as few instructions as possible.
 //   rows r = 0..NRT-1: [x box (NX) | torque (NQ) | collision (MR) | safe-set (1)]; "general" rows are the last NRC
 template <int NQ> struct QpLayout {
     static constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ;
@@ -67,8 +71,8 @@ template <int NQ> struct QpLayout {
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
     int nC;                                                     // doubles of the compact general rows
-    int oC, oIMG, oW, oSL, oAUX, oR0, oR1, oR2, oR3;            // 16-byte aligned blocks
-    int oZ, oZN, oGH0, oA1, oA2, oPB, oPART;
+    int oC, oIMG, oW, oSL, oPART, oWC, oAUX, oR0, oR1, oR2, oCZA, oCZN;
+    int oZ, oZN, oGH0, oA12;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
         MR = n_rows;
@@ -88,23 +92,24 @@ template <int NQ> struct QpLayout {
         // general rows without their structural zeros: [torque rows NQ x NZP | collision rows MR x NQP (the q columns) |
         // safe-set row NX (the x columns)]; the forward sweeps scatter the pieces into a row-major NRC x NZP image in LDS
         nC = NQ * NZP + MR * NQP + NX;
-        oC = o; o += nC;
-        oIMG = o; o += nIMG;
-        oW = o; o += NQ * KS;              // factor rows [W_i | w_i | . | row i of L^-1]
-        oSL = o; o += 2;                   // [soft weight, b != 0]
-        oAUX = o; o += 2 * NX;             // per state lane, as pairs: [b_i, soft weight]  (one load in the forward sweeps)
-        oR0 = o; o += NRT * 2;             // per row, as arrays of pairs: [lo, hi]
-        oR1 = o; o += NRT * 2;             //   [t_l, t_u]        (the soft row has no upper side: its slack lives in t_u)
-        oR2 = o; o += NRT * 2;             //   [lambda_l, lambda_u]
-        oR3 = o; o += NRT * 2;             //   [c.z_aff, c.z+]   (F1 -> B2/F2/B1, F2 -> B1)
-        oZ = o; o += NZ;
-        oZN = o; o += NZ;
-        oGH0 = o; o += NZ;                 // predictor gradient g + C^T e0 (B1 -> B2)
-        oA1 = o; o += NZ;                  // C^T e1, C^T e2: the corrector gradient is gh0 + sigma mu a1 + cw a2 (F1 -> B2)
-        oA2 = o; o += NZ;
-        oPB = o; o += NX;                  // P b
-        oPART = o; o += 4;                 // setup partials [R0, sum lambda t, count, node-0 rows infeasible]
-        stride = qp_even_c(o);
+        oC = o; o += qp_al8(nC);
+        oIMG = o; o += qp_al8(nIMG);
+        oW = o; o += qp_al8(NQ * KS);      // factor rows [W_i | w_i | . | row i of L^-1]
+        oSL = o; o += 16;                  // [soft weight, b != 0, ., . | setup partials: R0, sum lambda t, count, node-0 rows
+        oPART = oSL + 4;                   //  infeasible | the corrector's w (B2 -> F2; one whole 64-byte sector)]
+        oWC = oSL + 8;
+        oAUX = o; o += qp_al8(2 * NX);     // per state lane, as pairs: [b_i, soft weight]  (one load in the forward sweeps)
+        oR0 = o; o += qp_al8(NRT * 2);     // per row, as arrays of pairs: [lo, hi]
+        oR1 = o; o += qp_al8(NRT * 2);     //   [t_l, t_u]        (the soft row has no upper side: its slack lives in t_u)
+        oR2 = o; o += qp_al8(NRT * 2);     //   [lambda_l, lambda_u]
+        oCZA = o; o += 32;                 // per row lane: c.z_aff (F1 -> F2, B1) and c.z+ (F2 -> B1), each its own contiguous array
+        oCZN = o; o += 32;                 //   (as the two halves of a pair, each sweep's store was a read-modify-write of every sector)
+        oZ = o; o += qp_al8(NZ);
+        oZN = o; o += qp_al8(NZ);
+        oGH0 = o; o += qp_al8(NZ);         // predictor gradient g + C^T e0 with P b folded in: + [B^T P b; A^T P b] (B1 -> B2)
+        oA12 = o; o += qp_al8(2 * NZ);     // pairs (C^T e1, C^T e2): the corrector gradient is gh0 + sigma mu a1 + cw a2 (F1 -> B2)
+        static_assert(NQ <= 8, "the corrector's w shares a 16-double block with the stage scalars");
+        stride = (o + 15) & ~15;
     }
     __host__ __device__ size_t per_instance(int N) const { return (size_t)stride * (N + 1); }
 };
@@ -496,14 +501,15 @@ __global__ __launch_bounds__(32 * EV_TILE) void k_qp_setup(const smpc_problem_de
         if (r < NRT) {
             stnt_su(dbl2{tl, tu}, reinterpret_cast<dbl2*>(w + Ly.oR1) + r);
             stnt_su(dbl2{ll, lu}, reinterpret_cast<dbl2*>(w + Ly.oR2) + r);
-            stnt_su(dbl2{0.0, 0.0}, reinterpret_cast<dbl2*>(w + Ly.oR3) + r);
         }
+        stnt_su(0.0, w + Ly.oCZA + hl);   // (32 entries each: one per lane)
+        stnt_su(0.0, w + Ly.oCZN + hl);
         sE[r] = -(ll - lu);
     }
-    if (hl < 2) stnt_su(hl == 0 ? wsoft : bflag, w + Ly.oSL + hl);
+    if (hl < 4) stnt_su(hl == 0 ? wsoft : (hl == 1 ? bflag : 0.0), w + Ly.oSL + hl);
+    if (hl < 8) stnt_su(0.0, w + Ly.oWC + hl);
     if (hl < NX) stnt_su(dbl2{sB[hl], wsoft}, reinterpret_cast<dbl2*>(w + Ly.oAUX) + hl);
     if (hl < NZ) { stnt_su(sZ0[hl], w + Ly.oZ + hl); stnt_su(sZ0[hl], w + Ly.oZN + hl); }
-    if (hl < NX) stnt_su(0.0, w + Ly.oPB + hl);
     lds_fence();
     // stationarity residual at the initial point (pi = 0): g - C^T (ll - lu); dx_0 does not enter (no cost cross term)
     if (hl < NZ && !(k == 0 && hl >= NU) && !(last && hl < NU)) {
@@ -615,6 +621,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sWT = sIMG + O_WT;
     double* const sHXX = sIMG + O_HXX;
     static_assert(CST_MAX + 2 * NQ * KS <= O_PVA - O_TD, "staging area of the forward sweeps");
+    static_assert(NQ * KS <= NZ * NQP + NQ * MRP_MAX, "B1 lays the factor block out in the scaled-rows buffers before storing it");
     double* const sCst = sIMG + O_TD;                      // forward sweeps only: general rows ...
     double* const sWstA = sIMG + O_TD + CST_MAX;           // ... and the factor block, double-buffered (B2: single)
     double* const sPB = sIMG + O_PB;
@@ -745,9 +752,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                 for (int j = 0; j < IMG_PF; j++) img[j] = ldnt(s2 + min(hl + 32 * j, img_n2 - 1));
                 const dbl2 r0 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR0) + hr), r1 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR1) + hr),
-                           r2 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR2) + hr), r3 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR3) + hr);
+                           r2 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR2) + hr);
                 rs.lo = r0.x; rs.hi = r0.y; rs.tl = r1.x; rs.tu = r1.y; rs.ll = r2.x; rs.lu = r2.y;
-                czar = r3.x; cznr = r3.y;
+                czar = ldnt_s(w + Ly.oCZA + hr);
+                cznr = ldnt_s(w + Ly.oCZN + hr);
                 slb = ldnt_s(reinterpret_cast<const dbl2*>(w + Ly.oSL));
                 zc = ldnt_s(w + Ly.oZ + hz);
                 znc = ldnt_s(w + Ly.oZN + hz);
@@ -790,8 +798,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                         for (int jx = 0; jx < NX; jx++) a = fma(Pc[hl_x * NX + jx], sB[jx], a);
                     }
-                    sPB[hl_x] = a;
-                    stnt_s(a, w + Ly.oPB + hl_x);
+                    sPB[hl_x] = a;   // (reaches the corrector's backward sweep folded into the stored gradient, below)
                 }
                 // (fixed trip counts with clamped indices instead of data-dependent loop bounds: the passes of one loop are
                 //  independent, and only a fully unrolled loop lets the scheduler overlap their LDS round trips)
@@ -870,7 +877,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         if (ix < NQ)
                             for (int r = 0; r < MR; r++) gh = fma(sGT[ix * MRP + r], sE[rC0 + r], gh);
                     }
-                    stnt_s(gh, w + Ly.oGH0 + hz);   // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one
+                    // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one.  Its recursion needs P b only as
+                    // B^T P b (controls) and A^T P b (states), both constants of the iteration: stored with the gradient, so B2
+                    // loads no P b (sPB of this stage was written before the last fence; it is zero at the end stage)
+                    {
+                        double ghs = gh;
+                        if (!last) {
+                            if (hz < NU) ghs += cB * sPB[hz] + dt * sPB[NQ + hz];
+                            else ghs += hl_px < NQ ? sPB[hl_px] : dt * sPB[hl_px - NQ] + sPB[hl_px];
+                        }
+                        stnt_s(ghs, w + Ly.oGH0 + hz);
+                    }
                     if (last) {
                         if (hz >= NU) pvn[hz - NU] = gh;
                     } else if (hl < NU) {
@@ -903,10 +920,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             for (int i = 0; i < NQ; i++) sWT[hc * NQP + i] = col[i];
                             if (NQP > NQ) sWT[hc * NQP + NQ] = 0.0;   // (the other sweeps stage their blocks over this buffer)
                         }
+                        // the block goes out as whole 16-byte pieces (WST_PF store instructions instead of NQ narrow ones: this
+                        // stream pays per store): laid out in the scaled-rows buffer, which is dead since the assembly
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) stnt_b1(col[i], w + Ly.oW + i * KS + hc);
+                        for (int i = 0; i < NQ; i++) sTD[i * KS + hc] = col[i];
                     }
                     lds_fence();
+                    {
+                        const dbl2* s2 = reinterpret_cast<const dbl2*>(sTD);
+                        dbl2* d2 = reinterpret_cast<dbl2*>(w + Ly.oW);
+#pragma unroll
+                        for (int j = 0; j < WST_PF; j++) {
+                            const int pc = min(hl + 32 * j, W_N2 - 1);
+                            stnt_b1(s2[pc], d2 + pc);
+                        }
+                    }
                     QPT(3);
                     if (k > 0) {
                         // P_k = Hxx + A^T P A - W^T W (upper triangle, mirrored into the other buffer) and p_k
@@ -979,7 +1007,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             // issued after stage k's rows had been consumed, ~0.6 of a stage ahead -- under full load less than the memory
             // latency, and the row phase of every forward stage stalled for the difference: 1.0 M of the 5.2 M clocks of a
             // half-wave, profiles/r02_qp_phase_profile.txt.)
-            struct RSet { dbl2 r0, r1, r2, r3; double bi, wsoft; };
+            struct RSet { dbl2 r0, r1, r2; double cza, wc, bi, wsoft; };
             RSet RA, RB;
             // where piece j of this lane goes in the row-major LDS image (in doubles).  Piece 0 is always in the torque rows,
             // which the two layouts share; the collision / safe-set pieces move behind their rows' zero u columns.
@@ -1023,7 +1051,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 R.r0 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR0) + hr);
                 R.r1 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR1) + hr);
                 R.r2 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR2) + hr);
-                if (CORR) R.r3 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oR3) + hr);
+                if (CORR) {
+                    R.cza = ldnt_s(w + Ly.oCZA + hr);
+                    R.wc = ldnt_s(w + Ly.oWC + hl_u);   // the corrector's w (B2)
+                }
                 const dbl2 aux = ldnt_s(reinterpret_cast<const dbl2*>(w + Ly.oAUX) + hl_x);
                 R.bi = aux.x;
                 R.wsoft = aux.y;
@@ -1060,7 +1091,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
                     const double* wr_ = wc_ + hl_u * KS;
-                    double a = wr_[NX];
+                    double a = CORR ? cur.wc : wr_[NX];
 #pragma unroll
                     for (int j = 0; j < NX; j++) a = fma(wr_[j], xb[j], a);
                     if (hl < NQ) sRho[hl] = a;
@@ -1096,15 +1127,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     if (!CORR) {
                         double e1, e2;
                         qp_row_dir<true>(rs, soft, wsoft, cz, 0.0, 0.0, cz, &rr, &s1_, &s2_, &e1, &e2);
-                        stnt_s(cz, w + Ly.oR3 + 2 * hr);
+                        stnt_s(cz, w + Ly.oCZA + hr);
                         sD[hr] = e1;     // (B1's D / E arrays are free during the forward sweeps)
                         sE[hr] = e2;
                     } else {
-                        // (both halves of the pair are read: a loaded-but-unread register would be handed out again while the
-                        //  load is in flight, which costs a full vmcnt(0) at that point)
-                        const double cza = fma(0.0, cur.r3.y, cur.r3.x);
-                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, cza, &rr, &s1_, &s2_, nullptr, nullptr);
-                        stnt_s(cz, w + Ly.oR3 + 2 * hr + 1);
+                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, cur.cza, &rr, &s1_, &s2_, nullptr, nullptr);
+                        stnt_s(cz, w + Ly.oCZN + hr);
                         stnt_s(hz < NU ? sZU[hl_u] : xb[hl_px], w + Ly.oZN + hz);
                     }
                     S1 += row_live ? s1_ : 0.0;
@@ -1124,8 +1152,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             a2 = fma(c, sE[NX + r], a2);
                         }
                     if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
-                    stnt_s(a1, w + Ly.oA1 + hz);
-                    stnt_s(a2, w + Ly.oA2 + hz);
+                    stnt_s(dbl2{a1, a2}, reinterpret_cast<dbl2*>(w + Ly.oA12) + hz);
                     lds_fence();   // (the next stage overwrites the staged rows)
                 }
                 { const int t = o_xb; o_xb = o_xn; o_xn = t; }
@@ -1161,17 +1188,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         // ---------------- sweep B2: costate recursion of the corrector with the stored factors -------------------------------
         // ~100 instructions per stage: loads run THREE stages ahead (three register sets, the loop unrolled by three)
         {
-            struct BSet { double gh0, a1, a2, pb1, pb2; dbl2 Ws[WST_PF]; };
+            struct BSet { double gh0; dbl2 a12; dbl2 Ws[WST_PF]; };
             // the two entries of P b this lane needs: controls (i, NQ+i), states (ix, ix-NQ)
             const int ip1 = hl < NU ? hl : hl_px;
             const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
             auto load_b = [&](BSet& S, int k) {
                 const double* w = stage_ptr(k);
                 S.gh0 = ldnt_s(w + Ly.oGH0 + hz);
-                S.a1 = ldnt_s(w + Ly.oA1 + hz);
-                S.a2 = ldnt_s(w + Ly.oA2 + hz);
-                S.pb1 = ldnt_s(w + Ly.oPB + ip1);
-                S.pb2 = ldnt_s(w + Ly.oPB + ip2);
+                S.a12 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oA12) + hz);
                 const int kf = k < N ? k : N - 1;   // (there are no factors at the end stage)
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(kf) + Ly.oW);
 #pragma unroll
@@ -1182,7 +1206,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 asm volatile("; QPMARK B2_BEGIN");
                 double* w = stage_ptr(k);
                 const int kp = k > 3 ? k - 3 : 0;
-                const double gh = S.gh0 + sigmu * S.a1 + corr_w * S.a2;
+                const double gh = S.gh0 + sigmu * S.a12.x + corr_w * S.a12.y;   // (P b is inside gh0: B1)
                 if (last) {
                     if (hz >= NU) pvn[hz - NU] = gh;
                     // (the factor pieces of this set are never used: consume them so that their registers stay reserved)
@@ -1198,7 +1222,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                         for (int j = 0; j < WST_PF; j++) d2[min(hl + 32 * j, W_N2 - 1)] = S.Ws[j];
                     }
-                    const double q1 = pvc[ip1] + S.pb1, q2 = pvc[ip2] + S.pb2;
+                    const double q1 = pvc[ip1], q2 = pvc[ip2];
                     if (hl < NU) sRho[hl] = gh + cB * q1 + dt * q2;
                     load_b(S, kp);
                     lds_fence();
@@ -1208,7 +1232,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                         for (int j = 0; j < NQ; j++) v = fma(sWstA[hl_u * KS + LC0 + j], sRho[j], v);
                         if (hl < NQ) sWv[hl] = v;
-                        stnt_s(v, w + Ly.oW + hl_u * KS + NX);   // the corrector's w (F2 reads it with the block)
+                        // the corrector's w: one 64-byte sector of its own (inside the factor block it was NQ separate
+                        // read-modify-writes); lanes NQ.. hold the last entry again and fill the sector
+                        stnt_s(v, w + Ly.oWC + (hl < 8 ? hl : NQ - 1));
                     }
                     lds_fence();
                     if (k > 0 && hz >= NU) {
