@@ -164,7 +164,8 @@ def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=10.0, latency_solves=160):
 
 def launch_children(args):
     """`python bench.py --gpus N` without a launcher: N fresh children, one per GPU, started before this process touches a GPU
-    (device_count() does not initialise one).  Children inherit stdout: rank 0 prints the JSON line."""
+    (device_count() only counts -- where it does go through the HIP runtime in the parent that is harmless here: the ranks are
+    fresh child processes, never an exec of this one).  Children inherit stdout: rank 0 prints the JSON line."""
     import torch
     have = torch.cuda.device_count()
     if have < args.gpus:

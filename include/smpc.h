@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 3
+#define SMPC_ABI_VERSION 4
 
 #define SMPC_MAX_NQ 7
 #define SMPC_MAX_NX 14
@@ -304,6 +304,8 @@ typedef struct {                    /* the driver's per-instance state (scripts/
     int64_t* step;                  /* [1]: the step counter j */
     double *x_log, *u_log;          /* step-major logs [n_steps+1][B][nx], [n_steps][B][nu] */
     int64_t* r_log;                 /* [n_steps][B] receding index used at each step, -1 where none (or NULL) */
+    uint8_t* resumed;               /* [B]: written by smpc_loop_pre -- the instance left its backup trajectory at THIS step and
+                                       steps its controller again (scripts/mpc.py:137-141); may be NULL */
 } smpc_loop_state;
 
 /* scripts/mpc.py:130-151 before the controller's step: PD tracking of the backup trajectory / hold / resume for the instances
@@ -311,10 +313,21 @@ typedef struct {                    /* the driver's per-instance state (scripts/
 int smpc_loop_pre(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, const int64_t* r, const uint8_t* pending,
                   double* u_other, uint8_t* stepping);
 
+/* What the driver makes of the aborts the controllers raised in this step (abort[B] = smpc_policy_step's abort_out, updated
+ * in place).  An abort raised by an instance that stepped normally is an abort EVENT (scripts/mpc.py:161-190: viable state
+ * recorded, backup OCP solved): it stays set.  An abort raised on the very step an instance resumed MPC after a backup
+ * trajectory (ls->resumed) happens inside the `if sa_flag:` branch of the reference (mpc.py:137-141), where no event is
+ * opened: the instance simply is in safe abort again -- old backup trajectory, abort clock still running -- and re-tests its
+ * velocity next step.  With reference_quirks != 0 that is what happens here (sa[b] = 1, abort[b] = 0); with 0 every abort is an
+ * event.  *any_event (one int32) = 1 if an event remains, else 0. */
+int smpc_loop_classify_aborts(smpc_handle* h, int B, const smpc_loop_state* ls, int reference_quirks, uint8_t* abort,
+                              int32_t* any_event);
+
 /* scripts/mpc.py:161-190, second half: the n_c abort events of the previous step, applied once their backup OCPs (solved as a
  * compact batch, possibly on another handle / stream that the caller has ordered before this call) are known.  rows[n_c] =
  * instance of each event, status_c[n_c] / x_c[n_c][Nb+1][nx] / u_c[n_c][Nb][nu] = the backup solves.  Solved: the instance
- * follows its backup trajectory from this step on (u[b] = PD law on its first node, clock 1), flagged viable; failed: lost at
+ * follows its backup trajectory from this step on (u[b] = PD law on its first node, clock 1), viable[b] += 1 (a saturating
+ * count: mpc.py:189 appends the instance to viable_idx once per event and :277-278 removes it once); failed: lost at
  * the step of the event.  pending[b] (the flag smpc_loop_pre reads) is cleared.  Between the event and this call an instance
  * only has to be kept from stepping, which is what lets the backup solve overlap the next step's solve. */
 int smpc_loop_apply_backup(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, int n_c, const int64_t* rows,

@@ -939,13 +939,16 @@ bool build_qp(const smpc_problem_desc& D, int N, const double* lo_st, const doub
         }
         {
             bool on = nn_active(D, k, N, pk);
+            double w = k == N ? D.nn_soft_e : D.nn_soft_run;
+            if (zl_st && w >= 0.0) w = zl_st[k];   /* cost_set(k,'zl',.) (controller.py:455-468) on a soft row */
+            /* a zero slack weight leaves the row without effect on the optimum (the slack absorbs it at no cost): the reference
+               only ever writes zl = 0 together with p[4] = -1 (row off, :455-460); treated as "row absent" in either case */
+            if (zl_st && (k == N ? D.nn_soft_e : D.nn_soft_run) >= 0.0 && w == 0.0) on = false;
             for (int j = 0; j < nx; j++) s.Cm[r][o + j] = on ? e.nn_grad[j] : 0.0;
             s.lo[r] = 0.0 - e.nn_val;
             s.hi[r] = 1e6;
             s.has_lo[r] = on;
             s.has_hi[r] = false;
-            double w = k == N ? D.nn_soft_e : D.nn_soft_run;
-            if (zl_st && w >= 0.0) w = zl_st[k];   /* cost_set(k,'zl',.) (controller.py:455-468) on a soft row */
             s.soft[r] = on ? w : -1.0;
             r++;
         }

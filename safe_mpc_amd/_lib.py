@@ -18,7 +18,7 @@ SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error',
            'smpc_set_stage_bounds', 'smpc_set_slack_weights', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',
            'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_rollout_batch', 'smpc_sync', 'smpc_stream',
            'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing', 'smpc_get_qp_wave_stats', 'smpc_policy_step', 'smpc_loop_pre',
-           'smpc_loop_post', 'smpc_loop_apply_backup']
+           'smpc_loop_post', 'smpc_loop_apply_backup', 'smpc_loop_classify_aborts']
 
 
 class EngineError(RuntimeError):
@@ -44,7 +44,7 @@ class PolicyState(C.Structure):
 class LoopState(C.Structure):
     """smpc_loop_state"""
     _fields_ = [(k, _vp) for k in ('x_cur', 'alive', 'sa', 'collided', 'ja', 'last_x', 'last_u', 'x_abort', 'u_abort', 'step',
-                                   'x_log', 'u_log', 'r_log')]
+                                   'x_log', 'u_log', 'r_log', 'resumed')]
 
 
 def build(force=False):
@@ -98,5 +98,6 @@ def lib():
     L.smpc_loop_pre.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LoopState), dp, dp, dp, dp]
     L.smpc_loop_apply_backup.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LoopState), C.c_int, dp, dp, dp, dp, dp, dp, dp]
     L.smpc_loop_post.argtypes = [vp, C.c_int, C.POINTER(PolicyParams), C.POINTER(LoopState), dp, dp, dp]
+    L.smpc_loop_classify_aborts.argtypes = [vp, C.c_int, C.POINTER(LoopState), C.c_int, dp, dp]
     _lib = L
     return L

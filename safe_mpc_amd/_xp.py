@@ -31,7 +31,7 @@ class InPlaceState:
 class NumpyOps:
     name = 'numpy'
     on_device = False
-    f64, i64, i32, bool_ = np.float64, np.int64, np.int32, np.bool_
+    f64, i64, i32, bool_, u8 = np.float64, np.int64, np.int32, np.bool_, np.uint8
 
     def asarray(self, a, dtype=None):
         if type(a).__module__.startswith('torch'):
@@ -107,7 +107,7 @@ class TorchOps:
         import torch
         self.t = torch
         self.device = torch.device('cuda', int(device)) if not isinstance(device, torch.device) else device
-        self.f64, self.i64, self.i32, self.bool_ = torch.float64, torch.int64, torch.int32, torch.bool
+        self.f64, self.i64, self.i32, self.bool_, self.u8 = torch.float64, torch.int64, torch.int32, torch.bool, torch.uint8
 
     def asarray(self, a, dtype=None):
         t = self.t

@@ -256,7 +256,9 @@ class _Group(InPlaceState):
         self.x_abort = xp.zeros((B, self._Nb + 1, nx))
         self.u_abort = xp.zeros((B, self._Nb, nu))
         self.collided = xp.full((B,), False, xp.bool_)
-        self.viable = xp.full((B,), False, xp.bool_)
+        self.viable = xp.zeros((B,), xp.u8)            # successful abort events so far (mpc.py:189 appends once per event)
+        self.resumed = xp.full((B,), False, xp.bool_)   # left the backup trajectory at this step (mpc.py:137-141)
+        self._quirks = bool(getattr(params, 'reference_quirks', True))
         self.u = xp.zeros((B, nu))
         self.new_abort = xp.full((B,), False, xp.bool_)
         # last valid row of the state / input logs of every instance (mpc.py:114 pre-fills with NaN, :240-264 and :186-190 break)
@@ -277,6 +279,8 @@ class _Group(InPlaceState):
             # abort events: the backup OCPs of a step's events are solved on the backup solver's own stream WHILE the next
             # step's solve runs; until their outcome is applied (smpc_loop_apply_backup) the instances are only kept from stepping
             self._pending = xp.full((B,), False, xp.bool_)
+            self._resumed = xp.full((B,), False, xp.bool_)      # written by smpc_loop_pre
+            self._any_event = xp.zeros((1,), xp.i32)            # written by smpc_loop_classify_aborts
             self._inflight = None
             import torch
             bs = backup.ocp_solver
@@ -291,6 +295,8 @@ class _Group(InPlaceState):
             sv = ctrl.ocp_solver
             sv.loop_pre(self, getattr(ctrl, 'r', None), self._pending, self._u_other, self._stepping)
             ctrl.step_on_device(self.x_cur, self._stepping, self._u_other, u_out=self.u)
+            if ctrl.can_abort:
+                sv.loop_classify_aborts(self, self.new_abort, self._any_event)
             return
         kp, kd = 1.0, 1e2                                                               # mpc.py:97
         x_cur = self.x_cur
@@ -311,6 +317,7 @@ class _Group(InPlaceState):
             u = xp.where(still[:, None], u_h, u)
             self.sa = self.sa & ~resume
             self.ja = self.ja + xp.cast(in_abort, xp.i64)
+            self.resumed = resume
         else:
             u = self._zeros_u
         # --- instances under MPC (mpc.py:151)
@@ -325,6 +332,13 @@ class _Group(InPlaceState):
             u_m, ab = ctrl.step(x_cur)
         self.u = xp.where(stepping[:, None], u_m, u)
         self.new_abort = ab & stepping
+        if self._ever_aborted and self._quirks:
+            # An abort raised on the very step an instance resumed MPC sits inside the reference's `if sa_flag:` branch
+            # (mpc.py:137-141): no viable state is recorded and no backup OCP solved -- the instance is in safe abort again
+            # with its OLD backup trajectory, its abort clock keeps running, and it re-tests its velocity at the next step.
+            again = self.new_abort & self.resumed
+            self.sa = self.sa | again
+            self.new_abort = self.new_abort & ~again
 
     # ---- the step's host decision: abort events (mpc.py:161-190) -----------------------------------------------------------------
     def handle_aborts(self, j=None):
@@ -363,7 +377,7 @@ class _Group(InPlaceState):
         self.u_abort = xp.where(okb[:, None, None], ua_new, self.u_abort)
         self.ja = self.ja * xp.cast(~okb, xp.i64)
         self.sa = self.sa | okb
-        self.viable = self.viable | okb
+        self.viable = self.viable + xp.cast(okb, xp.u8)
 
     def _apply_inflight(self):
         if self._inflight is None:
@@ -382,7 +396,7 @@ class _Group(InPlaceState):
         import torch
         xp, ctrl, backup, Nb = self._xp, self._ctrl, self._backup, self._Nb
         self._apply_inflight()                               # the previous step's events (their first tracking control goes into u)
-        if not bool(ctrl._any_abort.item()):                 # (the step's one host synchronisation)
+        if not bool(self._any_event.item()):                 # (the step's one host synchronisation)
             return
         self._ever_aborted = True
         rows = np.where(xp.host(self.new_abort))[0]
@@ -479,9 +493,11 @@ class _Group(InPlaceState):
         x_last = np.nan_to_num(x_sim[:, -1])
         ev = solver.eval_nodes(xp.repeat_nodes(xp.asarray(x_last, xp.f64), ctrl.N + 1), xp.zeros((B, ctrl.N, ctrl.nu)), ctrl.p)
         ee = xp.host(ev['ee'])[:, 0, :]
-        conv = xp.host(self.alive) & ~np.isnan(x_sim[:, -1]).any(1) & (np.linalg.norm(ee - pr.ee_ref, axis=1) < params.tol_conv)
+        conv = ~np.isnan(x_sim[:, -1]).any(1) & (np.linalg.norm(ee - pr.ee_ref, axis=1) < params.tol_conv)
+        if not self._quirks:
+            conv &= xp.host(self.alive)        # (the reference tests x_sim[-1] even of an instance it has just recorded as failed)
         return dict(x=x_sim, u=u_sim, r_receding=np.transpose(xp.host(self.r_log), (1, 0))[:, :, None], conv=conv,
-                    collided=xp.host(self.collided), viable=xp.host(self.viable),
+                    collided=xp.host(self.collided), viable=xp.host(self.viable).astype(np.int64),
                     abort_events=[(e[0], e[1], e[2] if isinstance(e[2], np.ndarray) else xp.host(e[2])) for e in self._abort_events])
 
 
@@ -577,7 +593,13 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
     conv_idx = np.where(conv)[0].tolist()
     coll_idx = np.where(collided)[0].tolist()
     cs, ks = set(conv_idx), set(coll_idx)
-    viable_idx = [int(i) for i in np.where(viable)[0] if i not in cs and i not in ks]
+    if getattr(params, 'reference_quirks', True):
+        # mpc.py:189 appends an instance to viable_idx at EVERY abort event and :277-278 removes it ONCE when it converges: one that
+        # went through two events and converged is in both lists; a failure recorded at the last step does not stop the
+        # convergence test of :273 either (results(): conv is taken from x_sim[-1] alone)
+        viable_idx = [int(i) for i in np.where(viable - conv.astype(np.int64) > 0)[0] if i not in ks]
+    else:
+        viable_idx = [int(i) for i in np.where(viable)[0] if i not in cs and i not in ks]
     unconv_idx = sorted(set(range(B)) - cs - ks - set(viable_idx))
     # x_viable: one row per abort event, in the order the reference's loops produce them (instance-major, then time: mpc.py:102,125)
     ev = [e for o in outs for e in o['abort_events']]

@@ -41,7 +41,7 @@ struct smpc_handle {
     float* d_bias[SMPC_MAX_LAYERS] = {nullptr};
     // per-batch scratch, grown on demand
     int capB = 0;
-    double* d_ev = nullptr;       // linearisation records of the last call, 8-node interleaved tiles (device_model.hpp)
+    double* d_ev = nullptr;       // linearisation records of the last call, interleaved tiles of EV_TILE nodes (device_model.hpp)
     double* d_ws = nullptr;
     size_t ws_bytes = 0;
     int32_t *d_order = nullptr, *d_last_it = nullptr;  // longest-first dispatch order from the previous call's iterations
@@ -79,6 +79,7 @@ struct smpc_handle {
     int32_t* d_pol = nullptr;   // fails / accept counters of smpc_rollout_batch, [2][pol_B]
     int pol_B = 0;
     float last_ms[4] = {0, 0, 0, 0};
+    long mlp_rows_whole = 0;    // > 0 (a worker of smpc_rollout_batch): network rows of the WHOLE call, which selects the GEMM kernel
     char err[256] = "";
 };
 
@@ -224,8 +225,10 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
     const dim3 blk(256), grd(Mp / 128, H / 64);
     hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, MLP_KPAD, h->d_S, h->d_Wfwd[0], h->d_bias[0],
                        (const float*)nullptr, h->d_act[0], h->d_dg[0], live);
-    // hidden x hidden layers: LDS-tiled kernel once there are enough 128 x 128 tiles to fill the chip
-    const bool tiled = Mp >= 8192 && H % 128 == 0;
+    // hidden x hidden layers: LDS-tiled kernel once there are enough 128 x 128 tiles to fill the chip.  The two kernels sum K
+    // in different orders, so a sub-batch worker decides by the rows of the whole call (results do not depend on the split).
+    const long rows_sel = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128 : (long)Mp;
+    const bool tiled = rows_sel >= 8192 && H % 128 == 0;
     const dim3 grd_t(Mp / 128, H / 128);
     for (int l = 1; l + 1 < L; l++) {
         if (tiled)
@@ -847,8 +850,6 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
     const int N = h->N, nq = h->desc.nq, nx = 2 * nq;
     hipStream_t s = h->stream;
     int rc;
-    if ((rc = ensure_batch(h, B))) return rc;
-    if ((rc = ensure_io(h, B))) return rc;          // h->d_xo / d_uo receive each step's iterate
     const size_t nX = (size_t)B * (N + 1) * nx, nU = (size_t)B * N * nq, nP = (size_t)B * (N + 1) * SMPC_NP;
     const size_t sx = (size_t)B * nx, su = (size_t)B * nq;
     // device views of the arguments (host pointers: one staging allocation for the call)
@@ -903,10 +904,13 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
     if (n_sub < 1) n_sub = 1;
     if (n_sub > B) n_sub = B;
     if (h->inst_B == B) n_sub = 1;                       // per-instance stage bounds are held by this handle only
+    // (workspaces are allocated by whoever solves: the workers below when the batch is split -- the parent then holds none of
+    //  the QP workspace / linearisation records of the full batch -- otherwise this handle)
     rc = SMPC_OK;
     hipError_t e = hipMemcpyAsync(dxt, dx0, sizeof(double) * sx, hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return fail(h, SMPC_EHIP, "rollout init failed: %s", hipGetErrorString(e));
     if (n_sub > 1) {
+        h->timed = 0;      // (the solves run on the workers: smpc_get_timing on this handle reports "nothing timed", not stale numbers)
         if ((rc = rollout_workers(h, n_sub))) return rc;
         if (!h->ev_fork) HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         HIPCHK(h, hipEventRecord(h->ev_fork, s));        // inputs (staging copies, x_traj[0]) are ordered before the workers
@@ -918,6 +922,8 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
         const int lo = k * base + (k < rem ? k : rem), n = base + (k < rem ? 1 : 0);
         smpc_handle* w = n_sub > 1 ? h->kids[k] : h;
         if (n_sub > 1) HIPCHK(h, hipStreamWaitEvent(w->stream, h->ev_fork, 0));
+        const int nn_mode = h->desc.nn_mode;
+        w->mlp_rows_whole = n_sub > 1 ? (nn_mode == SMPC_NN_TERMINAL ? (long)B : (long)B * N) : 0;
         int rw;
         if ((rw = ensure_batch(w, n)) || (rw = ensure_io(w, n))) return fail(h, rw, "worker %d: %s", k, w->err);
         if (w->pol_B < n) {     // fails / accept counters of the policy (kept in the handle: the device path does not synchronise)
@@ -1063,7 +1069,20 @@ int smpc_loop_pre(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, cons
         return fail(h, SMPC_EINVAL, "loop state incomplete");
     (void)hipSetDevice(h->device);
     hipLaunchKernelGGL(k_loop_pre, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->desc.nq, Nb, ls->x_cur, ls->alive, ls->sa,
-                       ls->ja, ls->x_abort, ls->u_abort, r, ls->step, ls->r_log, u_other, stepping, pending);
+                       ls->ja, ls->x_abort, ls->u_abort, r, ls->step, ls->r_log, u_other, stepping, pending, ls->resumed);
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
+}
+
+int smpc_loop_classify_aborts(smpc_handle* h, int B, const smpc_loop_state* ls, int reference_quirks, uint8_t* abort,
+                              int32_t* any_event) {
+    if (!h) return SMPC_EINVAL;
+    if (B <= 0 || !ls || !abort || !any_event) return fail(h, SMPC_EINVAL, "bad argument");
+    if (!ls->sa) return fail(h, SMPC_EINVAL, "loop state incomplete");
+    (void)hipSetDevice(h->device);
+    HIPCHK(h, hipMemsetAsync(any_event, 0, sizeof(int32_t), h->stream));
+    hipLaunchKernelGGL(k_loop_classify_aborts, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, reference_quirks, ls->resumed,
+                       ls->sa, abort, any_event);
     HIPCHK(h, hipGetLastError());
     return SMPC_OK;
 }

@@ -301,7 +301,7 @@ __device__ unsigned long long g_qp_prof[16];
 
 
 // =========================================================================================================================
-// k_qp_setup: stage records + initial interior point, one half-wave per (instance, stage); a block = the 8 nodes of one
+// k_qp_setup: stage records + initial interior point, one half-wave per (instance, stage); a block = the EV_TILE nodes of one
 // interleaved tile of linearisation records (device_model.hpp), loaded by all its threads and taken apart in LDS
 // =========================================================================================================================
 template <int NQ, int MRT>
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(32 * EV_TILE) void k_qp_setup(const smpc_problem_de
     __shared__ __attribute__((aligned(16))) double smem[EV_TILE * HALF_D];
     static_assert(EV_TILE % 2 == 0 && EV_TILE <= 32, "one half-wave per node of a tile");
     {
-        // the tile: EV_TILE * EV_D doubles, contiguous; piece p holds element (2p) / 8 of nodes (2p) % 8 and (2p) % 8 + 1
+        // the tile: EV_TILE * EV_D doubles, contiguous; piece p holds element (2p) / EV_TILE of nodes (2p) % EV_TILE and the next one
         const dbl2* s2 = reinterpret_cast<const dbl2*>(ev + (size_t)blockIdx.x * (EV_TILE * EV_D));
         for (int p2 = threadIdx.x; p2 < EV_TILE * EV_D / 2; p2 += 32 * EV_TILE) {
             const dbl2 v = ldnt_su(s2 + p2);
@@ -363,7 +363,13 @@ __global__ __launch_bounds__(32 * EV_TILE) void k_qp_setup(const smpc_problem_de
     bool nn_on = false;
     if (D->nn_mode != SMPC_NN_NONE && k >= 1 && (D->nn_mode == SMPC_NN_ALL || last)) nn_on = pk[4] > 0.0;
     double wsoft = nn_on ? (last ? D->nn_soft_e : D->nn_soft_run) : -1.0;
-    if (zl_st && wsoft >= 0.0) wsoft = zl_st[k];    // cost_set(k, 'zl', .) on a row the formulation made soft
+    if (zl_st && wsoft >= 0.0) {
+        wsoft = zl_st[k];    // cost_set(k, 'zl', .) on a row the formulation made soft
+        // A zero weight leaves the row without effect on the optimum (its slack absorbs it at no cost) -- and would start the
+        // interior point ON the boundary of the multiplier's box [0, 0].  The reference only writes zl = 0 together with
+        // p[4] = -1 (controller.py:455-460); either way the row is absent.
+        if (wsoft == 0.0) { nn_on = false; wsoft = -1.0; }
+    }
 
     // general rows, row-major [torque | collision | safe-set] x [u q v]
     for (int el = hl; el < NRC * NZP; el += 32) {

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* 
 // ---- K2: torque row and Jacobians, one thread per (b, k) ------------------------------------------------------------------------
 // One forward and one backward recursion give tau, M = dtau/du, dtau/dq and dtau/dqd in closed form (rnea_deriv.hpp); every
 // entry is stored once, straight from the recursion into the node's (interleaved) record.  The thread index runs over ALL nodes,
-// so that 8 neighbouring lanes always belong to one tile; the terminal nodes (no torque row) idle.  (Round 1 ran 3 NQ
+// so that EV_TILE neighbouring lanes always belong to one tile; the terminal nodes (no torque row) idle.  (Round 1 ran 3 NQ
 // single-tangent dual-number passes per node in 3 NQ threads: 0.48 ms per 4096 x 30 nodes.)
 template <int NQ>
 __global__ __launch_bounds__(64) void k_node_torque(const smpc_problem_desc* __restrict__ D, int B, int N,

@@ -126,7 +126,7 @@ __global__ void k_loop_pre(int B, int nq, int Nb, const double* __restrict__ x_c
                            uint8_t* __restrict__ sa, int64_t* __restrict__ ja, const double* __restrict__ x_abort,
                            const double* __restrict__ u_abort, const int64_t* __restrict__ r_all, const int64_t* __restrict__ step,
                            int64_t* __restrict__ r_log, double* __restrict__ u_other, uint8_t* __restrict__ stepping,
-                           const uint8_t* __restrict__ pending) {
+                           const uint8_t* __restrict__ pending, uint8_t* __restrict__ resumed) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int nx = 2 * nq;
@@ -155,6 +155,7 @@ __global__ void k_loop_pre(int B, int nq, int Nb, const double* __restrict__ x_c
     //  outcome, it does not step: it will either follow the backup trajectory or be dead)
     const bool stp = alive[b] && !s_new && !(pending && pending[b]);
     stepping[b] = stp;
+    if (resumed) resumed[b] = resume && stp;
     if (r_log) r_log[(size_t)step[0] * B + b] = (stp && r_all) ? r_all[b] : -1;
 }
 
@@ -182,6 +183,21 @@ __global__ void k_loop_post(int B, int nq, const double* __restrict__ u, const d
 }
 
 __global__ void k_step_advance(int64_t* __restrict__ step) { step[0] += 1; }
+
+// scripts/mpc.py:137-141 vs :161-190: an abort raised on the step an instance resumed MPC opens no abort event -- the
+// instance is in safe abort again with its old backup trajectory and its abort clock still running (smpc.h,
+// smpc_loop_classify_aborts).
+__global__ void k_loop_classify_aborts(int B, int quirks, const uint8_t* __restrict__ resumed, uint8_t* __restrict__ sa,
+                                       uint8_t* __restrict__ abort, int32_t* __restrict__ any_event) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || !abort[b]) return;
+    if (quirks && resumed && resumed[b]) {
+        sa[b] = 1;
+        abort[b] = 0;
+    } else {
+        atomicOr(any_event, 1);
+    }
+}
 
 // The abort events of the PREVIOUS step (scripts/mpc.py:161-190), applied once their backup OCPs are solved: one thread per
 // event c (instance rows[c]).  Solved: the instance follows the backup trajectory from now on (this step applies its first node
@@ -212,7 +228,7 @@ __global__ void k_loop_apply_backup(int n_c, int nq, int Nb, const int64_t* __re
     for (int i = 0; i < (Nb + 1) * nx; i++) xa[i] = xs[i];
     for (int i = 0; i < Nb * nq; i++) ua[i] = us[i];
     sa[b] = 1;
-    viable[b] = 1;
+    viable[b] = viable[b] < 255 ? viable[b] + 1 : 255;
     ja[b] = 1;
     const double kp = 1.0, kd = 1e2;
     const double* x = x_cur + (size_t)b * nx;

@@ -352,7 +352,8 @@ class BatchedOcpSolver:
     def _loop_state(self, g):
         ptr = lambda t: t.data_ptr() if t is not None else None
         return _lib.LoopState(ptr(g.x_cur), ptr(g.alive), ptr(g.sa), ptr(g.collided), ptr(g.ja), ptr(g.last_x), ptr(g.last_u),
-                              ptr(g.x_abort), ptr(g.u_abort), ptr(g._jt), ptr(g.x_log), ptr(g.u_log), ptr(g.r_log))
+                              ptr(g.x_abort), ptr(g.u_abort), ptr(g._jt), ptr(g.x_log), ptr(g.u_log), ptr(g.r_log),
+                              ptr(getattr(g, '_resumed', None)))
 
     def loop_pre(self, g, r, pending, u_other, stepping):
         """scripts/mpc.py:130-151 for the group ``g`` (closed_loop._Group, device state)"""
@@ -360,6 +361,13 @@ class BatchedOcpSolver:
         with self._ordered(1):
             self._chk(self.L.smpc_loop_pre(self.h, g._B, g._Nb, C.byref(ls), r.data_ptr() if r is not None else None,
                                            pending.data_ptr() if pending is not None else None, u_other.data_ptr(), stepping.data_ptr()))
+
+    def loop_classify_aborts(self, g, abort, any_event):
+        """scripts/mpc.py:137-141 vs 161-190: which of this step's aborts open an abort event (smpc_loop_classify_aborts)"""
+        ls = self._loop_state(g)
+        quirks = int(bool(getattr(self.problem.params, 'reference_quirks', True)))
+        with self._ordered(1):
+            self._chk(self.L.smpc_loop_classify_aborts(self.h, g._B, C.byref(ls), quirks, abort.data_ptr(), any_event.data_ptr()))
 
     def loop_apply_backup(self, g, rows, status_c, x_c, u_c, viable, u, pending):
         """scripts/mpc.py:161-190 (second half) for the previous step's abort events, see smpc_loop_apply_backup"""

@@ -61,3 +61,19 @@ class OracleSolver:
 
     def sync(self):
         pass
+
+
+def make_double_controller(name, params, batch, N=None, cost='ext'):
+    """A policy-layer controller (safe_mpc_amd.controller) built around the CPU oracle instead of the HIP engine: what the
+    engine-backed controller is compared with in the tests (same class, same automaton, other numerics)."""
+    from safe_mpc_amd import controller as C
+    from safe_mpc_amd.safe_set import SafeSetNet
+    cls = C.SafeBackupController if name == 'backup' else C.CONTROLLERS[name]
+    N = int(N if N is not None else (params.back_hor if name == 'backup' else params.N))
+    prob = C.OcpProblem(params, cls.cont_name, 'zero' if name == 'backup' else cost, N=N)
+    net = SafeSetNet.from_params(params, prob.x_min, prob.x_max) if params.use_net else None
+    if net is not None:
+        prob.set_normalisation(net.mean, net.std)
+    ctrl = cls.__new__(cls)
+    C.AbstractController.__init__(ctrl, params, batch, 'zero' if name == 'backup' else cost, N, solver=OracleSolver(prob, net), net=net)
+    return ctrl

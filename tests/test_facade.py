@@ -83,6 +83,15 @@ def _cases(make_batched):
     bs3 = make_batched(prob3, net3)
     xb3, ub3, sb3, _ = bs3.solve(x0, xg, ug, p)
     out.append(('cost_set zl', st2 == sb3[0] and np.array_equal(ut2, ub3[0])))
+    # a ZERO slack weight with the row's switch left on: the row has no effect on the optimum and is treated as
+    # absent -- the same solve as with p[N][4] = -1 (and no interior point started on the boundary of a [0, 0] multiplier box)
+    f.cost_set(N, 'zl', np.zeros((1,)))
+    st4, xt4, ut4 = reference_solve_sequence(f, N, x0[0], xg[0], ug[0], traj, par.alpha)
+    p_off = p.copy()
+    p_off[:, N, 4] = -1.0
+    xb4, ub4, sb4, _ = bs.solve(x0, xg, ug, p_off)
+    out.append(('cost_set zl = 0', st4 == sb4[0] == 0 and np.array_equal(xt4, xb4[0]) and np.array_equal(ut4, ub4[0])))
+    f.cost_set(N, 'zl', par.ws_t * np.ones((1,)))
     # --- 3. RealReceding.step's state tube (controller.py:526-536) --------------------------------------------------------------
     par, prob, net = make_problem('real_receding', 'ext', N=10)
     bs = make_batched(prob, net)

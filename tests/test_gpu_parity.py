@@ -501,6 +501,110 @@ def test_policy_step_kernels_equal_numpy_automaton(name, B):
         assert n_abort > 0
 
 
+@pytest.mark.parametrize('name', ['st', 'constraint_everywhere', 'htwa', 'receding', 'real_receding'])
+def test_policy_step_kernels_equal_scalar_oracle(name):
+    """smpc_policy_step (kernels_policy.hpp) against oracle/policy_oracle.py -- the scalar, one-instance
+    restatement of controller.py:274-284, 369-388, 448-498, 524-565, 651-661 that shares no code with the product -- step by
+    step on kicked states, the oracle's numerics being the engine's own host path (one instance per call)."""
+    import torch
+    from oracle import policy_oracle as po
+    from policy_numerics import SolverNumerics
+    from safe_mpc_amd import controller as C
+    from safe_mpc_amd.parser import Parameters
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N = 6, 6, [12, 256, 1], 8
+    N, B = 8, 12
+    dev = C.get_controller(name, par, B, device_state=True)
+    x0 = sample_instances(dev.problem, B, seed=3, vel_scale=0.4)
+    xg, ug = np.repeat(x0[:, None, :], N + 1, axis=1), np.zeros((B, N, 6))
+    dev.setGuess(xg, ug)
+    host_solver = BatchedOcpSolver(dev.problem, dev.net)
+    insts, nums = [], []
+    for b in range(B):
+        inst = po.PolicyInstance(name, N, dev.nx, dev.nu, abort_flag=bool(par.abort_flag))
+        inst.set_guess(xg[b], ug[b])
+        inst.reset()
+        insts.append(inst)
+        nums.append(SolverNumerics(host_solver, dev.problem, par))
+    rng = np.random.default_rng(0)
+    x = x0.copy()
+    n_abort = n_fail = 0
+    for t in range(2 * N + 4):
+        ud, ad = dev.step_on_device(torch.tensor(x, device='cuda'))
+        dev.ocp_solver.sync()
+        ud, ad = ud.cpu().numpy(), ad.cpu().numpy()
+        for b in range(B):
+            uo, ao = po.step(insts[b], nums[b], x[b])
+            assert bool(ad[b]) == ao, (t, b)
+            # (the oracle integrates its guess in numpy, the engine in a kernel: rounding-level differences in the QP's data, which
+            #  the kicked, partly infeasible problems of this test amplify to ~1e-5 in single controls of size 1 next to others
+            #  of size 1e2..1e3 -- the automaton's integers below are compared exactly)
+            tol_u = 1e-4 * (1 + np.abs(uo).max())     # (= the RTI parity tolerance with the fp32 network in the loop)
+            assert np.abs(ud[b] - uo).max() < tol_u, (t, b)
+            assert int(dev.fails[b]) == insts[b].fails and int(dev.current_step[b]) == insts[b].current_step, (t, b)
+            assert np.abs(dev.x_guess[b].cpu().numpy() - np.array(insts[b].x_guess)).max() < 1e-5, (t, b)
+            ug_o = np.array(insts[b].u_guess)
+            assert np.abs(dev.u_guess[b].cpu().numpy() - ug_o).max() < 1e-4 * (1 + np.abs(ug_o).max()), (t, b)
+            if hasattr(dev, 'r'):
+                assert int(dev.r[b]) == insts[b].r, (t, b)
+            if dev.can_abort:
+                assert np.abs(dev.x_viable[b].cpu().numpy() - insts[b].x_viable).max() < 1e-5, (t, b)
+            n_abort += int(ao)
+            n_fail += int(insts[b].fails > 0)
+        x = x + par.dt * np.hstack([x[:, 6:], ud])
+        if t % 5 == 4:
+            x[:, 6:] += rng.normal(scale=0.5, size=(B, 6))
+        if t >= 2:
+            x[:max(B // 4, 1), 6] = 1.5 * dev.problem.x_max[6]       # pushed outside the velocity limits: reject / abort branches
+    if name != 'st':
+        assert n_fail > 0
+    if dev.can_abort:
+        assert n_abort > 0
+
+
+@pytest.mark.parametrize('name', ['htwa', 'receding'])
+def test_device_policy_loop_equals_scalar_oracle_loop(name):
+    """... and the whole closed loop with all state in HBM (run_mpc(on_device=True): smpc_loop_pre / smpc_policy_step /
+    smpc_loop_classify_aborts / smpc_loop_apply_backup / smpc_loop_post) against oracle/policy_oracle.py::run_closed_loop
+    (scripts/mpc.py:118-287 restated per instance): same abort events, receding indices, NaN patterns of the logs and
+    outcome lists; trajectories to the tolerance the zero-cost backup OCP allows."""
+    from oracle import policy_oracle as po
+    from policy_numerics import SolverNumerics
+    from safe_mpc_amd import closed_loop as cl
+    from safe_mpc_amd import controller as C
+    from safe_mpc_amd.parser import Parameters
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N, par.back_hor = 6, 6, [12, 256, 1], 10, 12
+    prob0 = C.OcpProblem(par, 'htwa', 'ext', N=10)
+    B, n_steps, cn = 40, 30, 1.0
+    x0 = sample_instances(prob0, B, seed=9, vel_scale=0.3)       # moving starts: some instances will have to abort
+    xg, ug = np.repeat(x0[:, None, :], 11, axis=1), np.zeros((B, 10, 6))
+    dev = cl.run_mpc(par, name, xg, ug, n_steps=n_steps, control_noise=cn, on_device=True, groups=1)
+    ctrl = C.get_controller(name, par, 1)
+    backup = C.SafeBackupController(par, 1)
+    outs = []
+    for b in range(B):
+        tau_noise = np.random.default_rng(b).normal(np.zeros(6), ctrl.problem.tau_max * cn / 100, 6)     # mpc.py:126, env_model.py:196
+        num = SolverNumerics(ctrl.ocp_solver, ctrl.problem, par, backup.ocp_solver, backup.problem, tau_noise=tau_noise)
+        inst = po.PolicyInstance(name, par.N, ctrl.nx, ctrl.nu, abort_flag=bool(par.abort_flag))
+        outs.append(po.run_closed_loop(inst, num, xg[b], ug[b], n_steps, backup.N, ctrl.nq, on_step=num.on_step))
+    xo, uo = np.array([r['x'] for r in outs]), np.array([r['u'] for r in outs])
+    assert np.array_equal(np.isnan(dev['x']), np.isnan(xo)) and np.array_equal(np.isnan(dev['u']), np.isnan(uo))
+    conv, coll, viable, unconv = po.outcome_lists(outs)
+    assert (dev['conv_idx'], dev['collisions_idx'], sorted(dev['viable_idx']), dev['unconv_idx']) == (conv, coll, sorted(viable), unconv)
+    ev = [(b, j, xv) for b, r in enumerate(outs) for (j, xv) in r['events']]
+    assert dev['x_viable'].shape[0] == len(ev)
+    if name == 'receding':
+        assert len(ev) > 0                       # (htwa needs N - 1 failures in a row: rare with a real solver; scripted on the CPU)
+    if ev:
+        assert np.abs(dev['x_viable'] - np.array([e[2] for e in ev])).max() < 1e-5
+    if name == 'receding':
+        assert np.array_equal(dev['r_receding'][:, :, 0], np.array([r['r'] for r in outs]))
+    assert np.nanmax(np.abs(dev['x'] - xo)) < 1e-4 and np.nanmax(np.abs(dev['u'] - uo)) < 2e-3 * (1 + np.nanmax(np.abs(uo)))
+
+
 def test_device_policy_loop_at_bench_size_invariants():
     """The receding policy with all state in HBM at the bench's batch size (4096 instances, N = 30, two pipelined groups, graph
     replay, asynchronous backup solves): size-independent properties of the result the reference's script would pickle."""
@@ -844,6 +948,33 @@ def test_generate_guess_merit_backtracking_on_engine():
     ctrl = C.get_controller('htwa', par, int(good.sum()))
     ctrl.x_temp, ctrl.u_temp = guess['xg'].copy(), guess['ug'].copy()
     assert np.all(ctrl.checkGuess())
+
+
+def test_generate_guess_engine_matches_oracle_double():
+    """guess generation (guess_acados.py:98-158: SQP with merit backtracking to
+    convergence, then checkGuess) run twice from the same 48 Halton starts -- once on the HIP engine, once on the CPU oracle
+    behind the same policy-layer code.  Same accepted set; warm starts equal within 1e-4 (1 + |.|inf) -- or, where the fp32
+    network's rounding tipped an Armijo test and the two SQP paths parted, the same final merit within 1e-6 relative (the
+    two then sit at the same local solution of the OCP) and checkGuess on both."""
+    from fake_solver import make_double_controller
+    from safe_mpc_amd import closed_loop as cl
+    from safe_mpc_amd.parser import Parameters
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N, par.nlp_max_iter = 6, 6, [12, 256, 1], 20, 200
+    he, hd = [], []
+    ge, good_e = cl.generate_guess(par, 'htwa', 48, history=he)
+    gd, good_d = cl.generate_guess(par, 'htwa', 48, make_controller=lambda n, b: make_double_controller(n, par, b), history=hd)
+    assert np.array_equal(good_e, good_d), (np.where(good_e)[0], np.where(good_d)[0])
+    assert good_e.sum() >= 24
+    xe, ue, xd, ud = ge['xg'], ge['ug'], gd['xg'], gd['ug']
+    ex = np.abs(xe - xd).reshape(len(xe), -1).max(1) / (1.0 + np.abs(xd).reshape(len(xd), -1).max(1))
+    eu = np.abs(ue - ud).reshape(len(ue), -1).max(1) / (1.0 + np.abs(ud).reshape(len(ud), -1).max(1))
+    close = (ex < 1e-4) & (eu < 1e-4)
+    me, md = he[-1]['merit'][good_e], hd[-1]['merit'][good_d]
+    same_merit = np.abs(me - md) <= 1e-6 * (1.0 + np.abs(md))
+    assert np.all(close | same_merit), (ex.max(), eu.max(), np.abs(me - md).max())
+    assert close.mean() >= 0.9, close.mean()                     # parting ways is the exception
+    assert np.all(he[-1]['violation'][good_e] < 1e-5) and np.all(hd[-1]['violation'][good_d] < 1e-5)
 
 
 def test_rollout_sub_batch_workers_change_nothing(monkeypatch):
