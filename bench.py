@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one closed-loop RTI-MPC step of the whole batch, all inputs resident in HBM:
-guessCorrection -> SQP-RTI solve (linearise, MLP, QP) -> accept test -> provideControl -> plant step
-(reference controller.py:274-284 + scripts/mpc.py:151,240 for every instance at once).
+<Controller>.step (guessCorrection -> SQP-RTI solve: linearise, MLP, QP -> accept test -> provideControl) -> plant step
+(reference controller.py:274-284 + scripts/mpc.py:151,240 for every instance at once).  The timed loop launches engine kernels
+only: the policy step is smpc_policy_step, the counters are kept by smpc_accumulate_stats.
 
 Workload (config.workload = "C1"): Z1-class 6-DoF, N = 30, 4096 OCP instances per GPU, controller 'st'
 (terminal soft safe-set row through the 12-256-256-256-1 GELU MLP), EXTERNAL cost with exact Hessian, 6 capsule pairs,
@@ -20,8 +21,11 @@ no launcher environment is present; under `python -m torch.distributed.run --npr
 reads RANK / LOCAL_RANK / WORLD_SIZE.  Asking for more GPUs than are visible is an error, never a silent 1-GPU run.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline:     algorithmic HBM bytes of the dominant kernel (k_qp_ipm) / its HIP-event duration vs 8 TB/s, the FP64 / MFMA
-                FLOP fractions SURVEY 8(d) asks for, and the launch's load balance (span / mean busy time of an instance)
+  roofline:     algorithmic HBM bytes of the dominant kernel (k_qp_ipm) / its HIP-event duration vs 8 TB/s (a probe launch over
+                the whole batch, alone on the GPU, at the state the timed loop ended in); `traffic` = measured HBM bytes per
+                instance-iteration (rocprofv3 --pmc passes, profiles/) x the probe's own iteration count; kernel_ms_in_loop =
+                HIP-event durations of the same kernels inside the timed loop (per sub-batch launch, three streams sharing the
+                chip); the FP64 / MFMA FLOP fractions SURVEY 8(d) asks for; the launch's load balance
   cpu_baseline: the CPU oracle (a port, not acados) timed on this host on a bounded sample of the SAME closed-loop state:
                 all-core throughput and 1-thread single-instance latency (p50 / p99, comparable to scripts/mpc.py:300-303).
 """
@@ -203,6 +207,11 @@ def main():
                          'independently and the long tail of one QP launch overlaps the bulk of another (measured r2: 1: 5.0, '
                          '2: 4.3, 3: 3.9, 4: 4.7 ms per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--noise', type=float, default=0.0,
+                    help='model noise in percent (BASELINE config 2): per-instance perturbed plants, 256 distinct draws of '
+                         'utils.py:138-166 laid out over the instances')
+    ap.add_argument('--control-noise', type=float, default=0.0, help='torque noise in percent of tau_max (env_model.py:196)')
+    ap.add_argument('--no-loop-timing', action='store_true', help='do not record per-kernel HIP events inside the timed loop')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
                     help='weak: --batch instances per GPU; strong: --batch instances in total, split over the GPUs')
     args = ap.parse_args()
@@ -263,28 +272,49 @@ def main():
 
     t = lambda a, dt=torch.float64: torch.tensor(a, dtype=dt, device=dev)
 
+    # model noise (BASELINE config 2, generate_urdf_noise.py:20-36): per-instance plants + one torque-noise draw per instance
+    jt_all = tn_all = None
+    if args.noise > 0:
+        from safe_mpc_amd.closed_loop import perturbed_joint_tables
+        small = perturbed_joint_tables(par, prob.nq, args.noise, np.arange(256))
+        jt_all = np.ascontiguousarray(small[(np.arange(B) + rank * B) % 256]).view(np.float64).reshape(B, prob.nq, -1)
+    if args.control_noise > 0:
+        tn_all = np.random.default_rng(1 + rank).normal(0.0, prob.tau_max * args.control_noise / 100, (B, nu))
+
+    # Results for rank 0: every sub-batch writes the applied control and the status of each step into its slice of a rollout
+    # log -- straight from the engine's kernels (u_out / status pointers of smpc_policy_step), no copy -- and ONE gather of the
+    # log ends the timed region ("once per step ... or once per rollout").  A per-step collective would need an
+    # event hand-off between the sub-batch streams and the collective's stream every step; measured on one GPU that
+    # re-synchronises the streams and costs 0.5-1.5 ms of the 3.9 ms step even with the collective itself skipped.
+    K_log = max(args.steps, 1)
+    log_bytes = K_log * B * (nu * 8 + 4)
+    gather_in = torch.empty((log_bytes,), dtype=torch.uint8, device=dev)
+    u_log = gather_in[:K_log * B * nu * 8].view(torch.float64).view(K_log, B, nu)
+    st_log = gather_in[K_log * B * nu * 8:].view(torch.int32).view(K_log, B)
+
+    from safe_mpc_amd.controller import get_controller
+
     class Sub:
         pass
     subs = []
     for i, sv in enumerate(solvers):
         lo, hi = shard_range(B, S, i)
         sb = Sub()
-        sb.solver, sb.n = sv, hi - lo
+        sb.solver, sb.n, sb.off = sv, hi - lo, lo
         sb.stream = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
         with torch.cuda.stream(sb.stream):
-            sb.x_sim, sb.xg, sb.ug, sb.p = t(x0_h[lo:hi]), t(xg_h[lo:hi]), t(ug_h[lo:hi]), t(p_h[lo:hi])
-            sb.out = (torch.empty_like(sb.xg), torch.empty_like(sb.ug), torch.empty(sb.n, dtype=torch.int32, device=dev),
-                      torch.empty(sb.n, dtype=torch.int32, device=dev))
-            sb.iters = torch.zeros((), dtype=torch.float64, device=dev)
-            sb.fails = torch.zeros((), dtype=torch.float64, device=dev)
-            sb.off = lo
+            # the reference's controller object for these instances, all of its state in HBM (safe_mpc_amd/controller.py)
+            sb.ctrl = get_controller(CONTROLLER, par, sb.n, cost='ext', N=N, solver=sv, net=net, device=local, device_state=True)
+            sb.ctrl.setGuess(t(xg_h[lo:hi]), t(ug_h[lo:hi]))
+            sb.ctrl.p.copy_(t(p_h[lo:hi]))
+            sb.x_sim, sb.x_next = t(x0_h[lo:hi]), t(x0_h[lo:hi])
+            sb.u_eff = torch.empty((sb.n, nu), dtype=torch.float64, device=dev)
+            sb.acc = torch.zeros((3,), dtype=torch.int64, device=dev)      # [sum of IPM iterations, failed solves, solves]
+            sb.jt = t(jt_all[lo:hi]) if jt_all is not None else None
+            sb.tn = t(tn_all[lo:hi]) if tn_all is not None else None
+            sb.status_home = sb.ctrl.last_status
+        sb.tsum, sb.tcnt = np.zeros(5), 0
         subs.append(sb)
-    # Results for rank 0: every sub-batch writes [u_apply | status] of each step into its slice of a rollout log; ONE gather of
-    # the log at the end of the timed steps ("once per step ... or once per rollout").  A per-step collective would
-    # need an event hand-off between the sub-batch streams and the collective's stream every step; measured on one GPU that
-    # re-synchronises the streams and costs 0.5-1.5 ms of the 3.9 ms step even with the collective itself skipped.
-    K_log = max(args.steps, 1)
-    gather_in = torch.empty((K_log, B, nu + 1), dtype=torch.float64, device=dev)
     if args.scaling == 'strong':
         sizes_all = [shard_range(args.batch, world, r)[1] - shard_range(args.batch, world, r)[0] for r in range(world)]
     else:
@@ -293,26 +323,28 @@ def main():
     gather_bufs = None
     if use_dist:
         from safe_mpc_amd.sharding import gather_buffers
-        gather_bufs = gather_buffers(gather_in.view(K_log * B, nu + 1), [K_log * n_r for n_r in sizes_all], rank)
+        gather_bufs = gather_buffers(gather_in.view(K_log * B, nu * 8 + 4), [K_log * n_r for n_r in sizes_all], rank)
 
     def sub_step(sb, first):
-        """One closed-loop step of one sub-batch, entirely on its stream, state updated in place (graph-capturable)."""
-        sv = sb.solver
-        if not first:
-            sv.guess_correction(sb.xg, sb.ug)                                     # controller.py:226-231
-        xt, ut, st, it = sv.solve(sb.x_sim, sb.xg, sb.ug, sb.p, out=sb.out)      # controller.py:136-167
-        accept = (st == 0).to(torch.int32)                                        # NaiveController.step (:279-283)
-        _, _, u_apply = sv.provide_control(accept, xt, ut, sb.xg, sb.ug)          # controller.py:169-184 (xg, ug in place)
-        xn, _ = sv.plant_step(sb.x_sim, u_apply)                                  # env_model.py:192-206 (nominal plant)
-        sb.x_sim.copy_(xn)
-        sb.iters.add_(it.sum())
-        sb.fails.add_((st != 0).sum())
-        if use_dist:
-            pay = gather_in[step_no[0] % K_log, sb.off:sb.off + sb.n]
-            pay[:, :nu] = u_apply
-            pay[:, nu] = st.to(torch.float64)
+        """One closed-loop step of one sub-batch, entirely on its stream: engine kernels only (graph-capturable when the log
+        slot is fixed).  <Controller>.step = guessCorrection, RTI solve, accept test, provideControl (controller.py:274-284 for
+        'st'; :651-661 for 'constraint_everywhere') as smpc_policy_step; then the plant (env_model.py:192-206)."""
+        sv, ctrl = sb.solver, sb.ctrl
+        fixed = bool(args.graphs)            # (--graphs 1: a captured step bakes its addresses in -- one log slot, state copied back)
+        slot = 0 if fixed else step_no[0] % K_log
+        u_slot = u_log[slot, sb.off:sb.off + sb.n]
+        if use_dist:      # the status of this step lands in the rollout log as well
+            object.__setattr__(ctrl, 'last_status', st_log[slot, sb.off:sb.off + sb.n])
+        ctrl.step_on_device(sb.x_sim, u_out=u_slot)
+        sv.plant_step(sb.x_sim, u_slot, sb.jt, sb.tn, out=(sb.x_next, sb.u_eff))
+        if fixed:
+            sb.x_sim.copy_(sb.x_next)
+        else:
+            sb.x_sim, sb.x_next = sb.x_next, sb.x_sim
+        sv.accumulate_stats(ctrl.last_status, ctrl.qp_iter, sb.acc)
 
     step_no = [0]
+    loop_timing = [False]
 
     def step(first):
         for sb in subs:
@@ -329,7 +361,7 @@ def main():
         for sb in subs:
             cur.wait_stream(sb.stream)
         if os.environ.get('SMPC_SKIP_NCCL') != '1':      # (diagnostic knob: everything but the collective itself)
-            gather_to_root(gather_in.view(K_log * B, nu + 1), sizes=[K_log * n_r for n_r in sizes_all], bufs=gather_bufs, concat=False)
+            gather_to_root(gather_in.view(K_log * B, nu * 8 + 4), sizes=[K_log * n_r for n_r in sizes_all], bufs=gather_bufs, concat=False)
 
     def barrier():
         for sb in subs:
@@ -360,8 +392,11 @@ def main():
                 sb.graph = None
         barrier()
     for sb in subs:
-        sb.iters.zero_()
-        sb.fails.zero_()
+        with torch.cuda.stream(sb.stream):
+            sb.acc.zero_()
+        if not args.no_loop_timing and sb.graph is None:
+            sb.solver.enable_timing(2)          # HIP events around each kernel group of every solve; read one step late
+    loop_timing[0] = not args.no_loop_timing and subs[0].graph is None
     barrier()
     t0 = time.perf_counter()
     step_no[0] = 0
@@ -371,12 +406,32 @@ def main():
         gather_results()
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-kernel HIP-event durations of the timed loop's own launches (the engine kept the events of each solver's last 64 solves)
+    for sb in subs:
+        for back in range(min(args.steps, 64) if loop_timing[0] else 0):
+            tm = sb.solver.timing_history(back)
+            if tm is not None:
+                sb.tsum += [tm['time_lin'], tm['time_nn'], tm['time_qp_setup'], tm['time_qp_ipm'], tm['time_tot']]
+                sb.tcnt += 1
+    loop_timing[0] = False
+    for sb in subs:
+        sb.solver.enable_timing(0)
+        if use_dist:
+            object.__setattr__(sb.ctrl, 'last_status', sb.status_home)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    mean_iter = sum(float(sb.iters.item()) for sb in subs) / (B * max(args.steps, 1))
-    fails = sum(float(sb.fails.item()) for sb in subs)
+    acc_all = sum(sb.acc.cpu().numpy().astype(np.int64) for sb in subs)
+    mean_iter = float(acc_all[0]) / max(int(acc_all[2]), 1)
+    fails = float(acc_all[1])
+    in_loop = None
+    if sum(sb.tcnt for sb in subs) > 0:
+        ts = sum(sb.tsum for sb in subs) / sum(sb.tcnt for sb in subs) * 1e3
+        in_loop = {'linearise': ts[0], 'mlp': ts[1], 'qp_setup': ts[2], 'qp_ipm': ts[3], 'solve_total': ts[4],
+                   'launches_sampled': int(sum(sb.tcnt for sb in subs)), 'instances_per_launch': [sb.n for sb in subs],
+                   'note': 'mean HIP-event duration per SUB-BATCH launch inside the timed loop (the sub-batch streams share the '
+                           'chip, so these overlap each other; their sum over the streams is not the step time)'}
 
     # roofline probe of the dominant kernel (k_qp_ipm): ONE launch over the whole batch, alone on the GPU, HIP events on
     # the engine's stream around each phase (the per-launch duration rocprofv3 --kernel-trace reports for the same launch)
@@ -385,8 +440,8 @@ def main():
         sv = BatchedOcpSolver(prob, net, device=local)
         st_ = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
         with torch.cuda.stream(st_):
-            xs = torch.cat([sb.x_sim for sb in subs]); xgf = torch.cat([sb.xg for sb in subs])
-            ugf = torch.cat([sb.ug for sb in subs]); pf = torch.cat([sb.p for sb in subs])
+            xs = torch.cat([sb.x_sim for sb in subs]); xgf = torch.cat([sb.ctrl.x_guess for sb in subs])
+            ugf = torch.cat([sb.ctrl.u_guess for sb in subs]); pf = torch.cat([sb.ctrl.p for sb in subs])
         torch.cuda.synchronize()
         sv.enable_timing(True)
         acc = np.zeros(8)
@@ -408,17 +463,22 @@ def main():
         qp_fl = qp_flops_per_iteration(prob.nq, N, nh) * it_probe * B
         mlp_rows = B if prob.desc.nn_mode == 1 else (B * N if prob.desc.nn_mode == 2 else 0)
         mlp_fl = mlp_flops_per_row(prob.nq) * mlp_rows
-        # HBM bytes per launch come from separate rocprofv3 --pmc passes over scripts/qp_bench.py (counters cannot be read from
-        # inside this process): committed file, named here; null when there is none for this round's kernel
-        traffic, traffic_rate, traffic_src = None, None, None
-        for name in ('r02_pmc_traffic.json',):
+        # HBM bytes come from separate rocprofv3 --pmc passes over scripts/qp_bench.py (counters cannot be read from inside this
+        # process).  The committed file holds bytes per INSTANCE-ITERATION of k_qp_ipm (the kernel's traffic is proportional to
+        # the iterations it runs); traffic of THIS probe launch = that x the probe's own iteration count x instances, so that
+        # traffic / kernel time is the rate of the launch that was timed here.  null when there is no file for this round's kernel.
+        traffic, traffic_rate, traffic_src, bpi = None, None, None, None
+        for name in ('r03_pmc_traffic.json',):
             tf = os.path.join(ROOT, 'profiles', name)
-            if os.path.exists(tf) and B == B_PER_GPU and CONTROLLER == 'st':
+            if os.path.exists(tf) and CONTROLLER == 'st':
                 tj = json.load(open(tf))
-                traffic, traffic_rate, traffic_src = tj['traffic_bytes_per_launch'], tj.get('traffic_GBps_in_pmc_run'), 'profiles/' + name
+                bpi = tj.get('bytes_per_instance_iteration')
+                if bpi:
+                    traffic = bpi * it_probe * B
+                    traffic_rate, traffic_src = traffic / acc[5] / 1e9, 'profiles/' + name
         roof = {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                'traffic_GBps_in_pmc_run': traffic_rate,
+                'traffic_bytes_per_instance_iteration': bpi, 'traffic_GBps': traffic_rate,
                 'flop_frac_qp_fp64': qp_fl / acc[5] / 1e12 / FP64_VALU_PEAK_TF,
                 'flop_frac_mlp_mfma': (mlp_fl / acc[1] / 1e12 / MFMA_F32_PEAK_TF) if mlp_rows and acc[1] > 0 else None,
                 'flops': {'qp_per_launch': qp_fl, 'qp_TFLOPs': qp_fl / acc[5] / 1e12, 'fp64_valu_peak_TFLOPs': FP64_VALU_PEAK_TF,
@@ -431,7 +491,9 @@ def main():
                                          '(smpc_get_qp_wave_stats); 1.0 = no time spent waiting for the slowest instances'},
                 'mean_ipm_iterations_in_probe': it_probe,
                 'kernel_ms': {'linearise': acc[0] * 1e3, 'mlp': acc[1] * 1e3, 'qp_setup': acc[4] * 1e3, 'qp_ipm': acc[5] * 1e3,
-                              'solve_total': acc[3] * 1e3},
+                              'solve_total': acc[3] * 1e3,
+                              'note': 'ONE launch over the whole batch, alone on the GPU (the roofline probe) -- not the timed loop'},
+                'kernel_ms_in_loop': in_loop,
                 'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={B}, alone on the GPU, closed-loop state after the timed steps'}
 
     cpu = None
@@ -448,7 +510,8 @@ def main():
             'value': total / elapsed, 'unit': 'instance-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True,
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': f'C1: Z1-class 6-DoF, N=30, {args.batch} instances' + ('/GPU' if args.scaling == 'weak' else ' in total') +
+            'config': {'workload': ('C2' if args.noise > 0 else 'C1') + f': Z1-class 6-DoF, N=30, {args.batch} instances' + ('/GPU' if args.scaling == 'weak' else ' in total') +
+                                   (f', model noise {args.noise}% (256 plant draws) + torque noise {args.control_noise}%' if args.noise > 0 or args.control_noise > 0 else '') +
                                    ', controller ' + CONTROLLER +
                                    (' (soft terminal NN row, ' if CONTROLLER == 'st' else ' (NN row as configured, ') +
                                    'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',

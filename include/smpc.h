@@ -181,6 +181,9 @@ const char* smpc_last_error(const smpc_handle* h);
  * device memory (on_device != 0: e.g. torch.Tensor.data_ptr() of a ROCm tensor); the handle keeps its own copy. */
 int smpc_set_mlp(smpc_handle* h, int nlayers, const int32_t* dims, const float* const* W, const float* const* b,
                  int on_device);
+/* the activation between the layers: parser.py:95-102 (`act_fun` of config.yaml:67); GELU(tanh) unless set */
+enum { SMPC_ACT_GELU_TANH = 0, SMPC_ACT_RELU = 1, SMPC_ACT_ELU = 2, SMPC_ACT_TANH = 3, SMPC_ACT_SILU = 4 };
+int smpc_set_mlp_activation(smpc_handle* h, int act);
 
 /* replaces ocp_solver.set_new_time_steps + update_qp_solver_cond_N (controller.py:208-209): change N without
  * re-creating; N <= SMPC_MAX_N */
@@ -345,12 +348,21 @@ int smpc_sync(smpc_handle* h);
 void* smpc_stream(smpc_handle* h);
 /* device time of the kernels of the last smpc_solve_batch, measured with HIP events on the handle's stream:
  * ms[0] linearise, ms[1] MLP, ms[2] QP, ms[3] total.  Mirrors ocp_solver.get_stats('time_lin'|'time_qp'|'time_tot')
- * (controller.py:123-124,192-193).  Only valid when timing was enabled. */
+ * (controller.py:123-124,192-193).  Only valid when timing was enabled.  on = 1: HIP events + the in-kernel load-balance probe of
+ * smpc_get_qp_wave_stats; on = 2: HIP events only (what a running loop can afford); 0: off. */
 int smpc_enable_timing(smpc_handle* h, int on);
 int smpc_get_timing(smpc_handle* h, float* ms4);
 /* Split of ms[2] of smpc_get_timing: ms2[0] = k_qp_setup (stage records + initial point), ms2[1] = k_qp_ipm (the interior-
  * point iterations) -- the per-kernel durations rocprofv3 --kernel-trace reports (acados: time_qp_solver_call). */
 int smpc_get_qp_timing(smpc_handle* h, float* ms2);
+/* The same durations for the solve `back` solves before the last one (0 = the last; the handle keeps the events of its last 64
+ * timed solves), without waiting: ms6 = {linearise, MLP, k_qp_setup, k_qp_ipm, total, valid}.  valid = 0 (and the rest 0) when
+ * there is no such solve or it has not finished yet.  Lets a loop that enqueues far ahead of the GPU collect per-kernel times of
+ * its own launches afterwards (bench.py: kernel_ms_in_loop). */
+int smpc_get_timing_history(smpc_handle* h, int back, float* ms6);
+/* acc3[0] += sum of qp_iter[B], acc3[1] += number of status[b] != 0, acc3[2] += B -- device-side counters of a closed loop
+ * (DEVICE pointers; qp_iter may be NULL), enqueued on the handle's stream. */
+int smpc_accumulate_stats(smpc_handle* h, int B, const int32_t* status, const int32_t* qp_iter, unsigned long long* acc3);
 /* Load balance of the last timed k_qp_ipm launch: out3[0] = mean busy time of a half-wavefront (= one instance), out3[1] =
  * first start to last end of any half-wavefront, both in microseconds of the constant 100 MHz clock, out3[2] = half-waves
  * counted.  out3[1] / out3[0] is the share of the launch spent waiting for its slowest instances. */

@@ -75,7 +75,9 @@ class Oracle:
         except Exception:
             pass
 
-    def set_mlp(self, weights, biases):
+    def set_mlp(self, weights, biases, act='gelu'):
+        code = {'gelu': 0, 'relu': 1, 'elu': 2, 'tanh': 3, 'silu': 4}[act]
+        assert self.L.orc_set_mlp_activation(self.h, code) == 0
         n = len(weights)
         Ws = [np.ascontiguousarray(w, np.float32) for w in weights]
         bs = [np.ascontiguousarray(b, np.float32) for b in biases]

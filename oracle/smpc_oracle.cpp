@@ -316,6 +316,7 @@ template <class T> T row_value(const smpc_problem_desc& D, const smpc_row& r, co
  * MLP in float32 (safe_set.py:26-43; torch evaluates the network in fp32 through l4casadi, safe_set.py:89-94)
  * ---------------------------------------------------------------------------------------------------------------- */
 struct Mlp {
+    int act = 0;      // SMPC_ACT_* (parser.py:95-102)
     int nlayers = 0;  // number of Linear layers
     int dims[SMPC_MAX_LAYERS + 1] = {0};
     std::vector<float> W[SMPC_MAX_LAYERS], b[SMPC_MAX_LAYERS];
@@ -327,6 +328,16 @@ inline float gelu_tanh(float a, float* dgelu) {
     float th = std::tanh(inner);
     *dgelu = 0.5f * (1.0f + th) + 0.5f * a * (1.0f - th * th) * k0 * (1.0f + 3.0f * k1 * a * a);
     return 0.5f * a * (1.0f + th);
+}
+/* the activations of parser.py:95-102 as torch.nn defines them: value and derivative */
+inline float activation(int act, float a, float* d) {
+    switch (act) {
+    case SMPC_ACT_RELU: *d = a > 0.0f ? 1.0f : 0.0f; return a > 0.0f ? a : 0.0f;                       /* nn.ReLU */
+    case SMPC_ACT_ELU: { float e = std::exp(a); *d = a > 0.0f ? 1.0f : e; return a > 0.0f ? a : e - 1.0f; }   /* nn.ELU, alpha = 1 */
+    case SMPC_ACT_TANH: { float t = std::tanh(a); *d = 1.0f - t * t; return t; }                      /* nn.Tanh */
+    case SMPC_ACT_SILU: { float s = 1.0f / (1.0f + std::exp(-a)); *d = s * (1.0f + a * (1.0f - s)); return a * s; }   /* nn.SiLU */
+    default: return gelu_tanh(a, d);                                                                   /* nn.GELU('tanh') */
+    }
 }
 /* y = net(s), grad = d y / d s; everything in fp32 like torch */
 void mlp_eval(const Mlp& net, const float* s, float* y, float* grad) {
@@ -342,7 +353,7 @@ void mlp_eval(const Mlp& net, const float* s, float* y, float* grad) {
             const float* w = &net.W[l][(size_t)o * ni];
             for (int i = 0; i < ni; i++) acc = std::fmaf(w[i], act[l][i], acc);
             acc += net.b[l][o];
-            if (l + 1 < L) acc = gelu_tanh(acc, &dact[l][o]);
+            if (l + 1 < L) acc = activation(net.act, acc, &dact[l][o]);
             act[l + 1][o] = acc;
         }
     }
@@ -1002,6 +1013,12 @@ int orc_set_mlp(void* h, int nlayers, const int32_t* dims, const float* const* W
         o->net.W[l].assign(W[l], W[l] + (size_t)dims[l] * dims[l + 1]);
         o->net.b[l].assign(b[l], b[l] + dims[l + 1]);
     }
+    return 0;
+}
+int orc_set_mlp_activation(void* h, int act) {
+    Oracle* o = (Oracle*)h;
+    if (act < SMPC_ACT_GELU_TANH || act > SMPC_ACT_SILU) return SMPC_EINVAL;
+    o->net.act = act;
     return 0;
 }
 int orc_set_horizon(void* h, int N) {

@@ -18,7 +18,8 @@ SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error',
            'smpc_set_stage_bounds', 'smpc_set_slack_weights', 'smpc_set_instance_bounds', 'smpc_solve_batch', 'smpc_eval_nodes', 'smpc_guess_correction',
            'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_rollout_batch', 'smpc_sync', 'smpc_stream',
            'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing', 'smpc_get_qp_wave_stats', 'smpc_policy_step', 'smpc_loop_pre',
-           'smpc_loop_post', 'smpc_loop_apply_backup', 'smpc_loop_classify_aborts']
+           'smpc_loop_post', 'smpc_loop_apply_backup', 'smpc_loop_classify_aborts', 'smpc_get_timing_history',
+           'smpc_accumulate_stats', 'smpc_set_mlp_activation']
 
 
 class EngineError(RuntimeError):
@@ -99,5 +100,8 @@ def lib():
     L.smpc_loop_apply_backup.argtypes = [vp, C.c_int, C.c_int, C.POINTER(LoopState), C.c_int, dp, dp, dp, dp, dp, dp, dp]
     L.smpc_loop_post.argtypes = [vp, C.c_int, C.POINTER(PolicyParams), C.POINTER(LoopState), dp, dp, dp]
     L.smpc_loop_classify_aborts.argtypes = [vp, C.c_int, C.POINTER(LoopState), C.c_int, dp, dp]
+    L.smpc_get_timing_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.smpc_accumulate_stats.argtypes = [vp, C.c_int, dp, dp, dp]
+    L.smpc_set_mlp_activation.argtypes = [vp, C.c_int]
     _lib = L
     return L

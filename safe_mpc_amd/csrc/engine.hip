@@ -34,6 +34,7 @@ struct smpc_handle {
     size_t inst_cap = 0;   // doubles allocated in d_lo_b / d_hi_b
     // network
     int nlayers = 0;
+    int act = SMPC_ACT_GELU_TANH;
     int dims[SMPC_MAX_LAYERS + 1] = {0};
     int H = 0;
     float* d_Wfwd[SMPC_MAX_LAYERS] = {nullptr};  // [K][N] = W^T (layer 0 padded to MLP_KPAD rows)
@@ -67,7 +68,13 @@ struct smpc_handle {
     // timing
     int timing = 0;
     int timed = 0;              // a solve has been timed since timing was enabled
-    hipEvent_t ev_t[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // a ring of timing-event sets, one per solve: a loop that enqueues far ahead of the GPU reads the per-kernel times of its
+    // last EV_RING solves afterwards (smpc_get_timing_history), without a synchronisation inside the loop
+    static constexpr int EV_RING = 64;
+    hipEvent_t ev_sets[EV_RING][5] = {};
+    hipEvent_t* ev_t = ev_sets[0];
+    int ev_cur = 0;
+    long timed_count = 0;       // solves timed since timing was enabled
     // sub-batch workers of smpc_rollout_batch: full handles on their own streams that borrow this handle's network weights
     std::vector<smpc_handle*> kids;
     bool borrowed_mlp = false;            // (a worker: the weight buffers belong to its parent)
@@ -213,18 +220,41 @@ int ensure_nn_idx(smpc_handle* h, size_t M) {
 // forward (and optionally backward) pass of the network over M rows whose states are found through (mode, N) in x.
 // mode 3: the rows are the compacted list h->d_nn_idx of live nodes; their count is only known on the device (h->d_nn_cnt), so
 // the grids cover all M candidate rows and the blocks past the count return at once.
-template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const double* d_x, bool backward) {
+// d_p / d_ev: when given and the pass ran as the fused kernel, the chain rule to the node records is done as well and *chained
+// is set (the caller then skips k_nn_chain).
+template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const double* d_x, bool backward, const double* d_p = nullptr,
+                              double* d_ev = nullptr, bool* chained = nullptr) {
     int rc;
     if ((rc = ensure_mlp(h, (size_t)M))) return rc;
     const int Mp = (M + 127) / 128 * 128, H = h->H, L = h->nlayers;
     hipStream_t s = h->stream;
     const int32_t* idx = mode == 3 ? h->d_nn_idx : nullptr;
     const int32_t* live = mode == 3 ? h->d_nn_cnt : nullptr;
+    if (chained) *chained = false;
+    // Few rows (the terminal row: M = B): the whole pass as ONE kernel, activations in LDS / registers (kernels_mlp.hpp).  The
+    // choice follows the rows of the whole call (mlp_rows_whole), like the tiled kernel's below.
+    {
+        const long rows_all = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128 : (long)Mp;
+        static const bool no_fused = getenv("SMPC_MLP_UNFUSED") != nullptr;     // (A/B knob)
+        if (!no_fused && rows_all < 8192 && H == MLPF_H && L == 4 && (!backward || (d_p && d_ev))) {
+            MlpWeights Wt;
+            for (int l = 0; l < SMPC_MAX_LAYERS; l++) { Wt.wf[l] = h->d_Wfwd[l]; Wt.wb[l] = h->d_Wbwd[l]; Wt.bias[l] = h->d_bias[l]; }
+            const dim3 grd((M + MLPF_ROWS - 1) / MLPF_ROWS), blk(256);
+            if (backward)
+                hipLaunchKernelGGL((k_mlp_fused<NQ, true>), grd, blk, 0, s, h->d_desc, M, N, mode, h->act, Wt, d_x, d_p, idx, live, h->d_y, d_ev);
+            else
+                hipLaunchKernelGGL((k_mlp_fused<NQ, false>), grd, blk, 0, s, h->d_desc, M, N, mode, h->act, Wt, d_x, d_p, idx, live, h->d_y,
+                                   (double*)nullptr);
+            HIPCHK(h, hipGetLastError());
+            if (chained) *chained = backward;
+            return SMPC_OK;
+        }
+    }
     hipLaunchKernelGGL((k_nn_features<NQ>), dim3((Mp + 255) / 256), dim3(256), 0, s, h->d_desc, M, Mp, N, mode, d_x,
                        h->d_S, idx, live);
     const dim3 blk(256), grd(Mp / 128, H / 64);
     hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, MLP_KPAD, h->d_S, h->d_Wfwd[0], h->d_bias[0],
-                       (const float*)nullptr, h->d_act[0], h->d_dg[0], live);
+                       (const float*)nullptr, h->d_act[0], h->d_dg[0], live, h->act);
     // hidden x hidden layers: LDS-tiled kernel once there are enough 128 x 128 tiles to fill the chip.  The two kernels sum K
     // in different orders, so a sub-batch worker decides by the rows of the whole call (results do not depend on the split).
     const long rows_sel = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128 : (long)Mp;
@@ -233,10 +263,10 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
     for (int l = 1; l + 1 < L; l++) {
         if (tiled)
             hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_BIAS_GELU>), grd_t, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
-                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live);
+                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live, h->act);
         else
             hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
-                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live);
+                               h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live, h->act);
     }
     hipLaunchKernelGGL(k_nn_output, dim3((Mp + 3) / 4), blk, 0, s, Mp, H, h->d_act[L - 2], h->d_dg[L - 2],
                        h->d_Wbwd[L - 1], h->d_bias[L - 1], h->d_y, h->d_dA, live);
@@ -245,14 +275,14 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
         for (int l = L - 2; l >= 1; l--) {
             if (tiled)
                 hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_MUL>), grd_t, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l],
-                                   (const float*)nullptr, h->d_dg[l - 1], nxt, (float*)nullptr, live);
+                                   (const float*)nullptr, h->d_dg[l - 1], nxt, (float*)nullptr, live, h->act);
             else
                 hipLaunchKernelGGL((k_gemm_f32<EPI_MUL>), grd, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l], (const float*)nullptr,
-                                   h->d_dg[l - 1], nxt, (float*)nullptr, live);
+                                   h->d_dg[l - 1], nxt, (float*)nullptr, live, h->act);
             float* t = cur; cur = nxt; nxt = t;
         }
         hipLaunchKernelGGL((k_gemm_f32<EPI_PLAIN>), dim3(Mp / 128, MLP_NPAD / 64), blk, 0, s, Mp, MLP_NPAD, H, cur,
-                           h->d_Wbwd[0], (const float*)nullptr, (const float*)nullptr, h->d_GS, (float*)nullptr, live);
+                           h->d_Wbwd[0], (const float*)nullptr, (const float*)nullptr, h->d_GS, (float*)nullptr, live, h->act);
     }
     HIPCHK(h, hipGetLastError());
     return SMPC_OK;
@@ -280,10 +310,12 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
             HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
             hipLaunchKernelGGL(k_nn_compact, dim3((M + 255) / 256), dim3(256), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
         }
-        if ((rc = run_mlp<NQ>(h, M, mode, N, d_xg, true))) return rc;
-        hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 255) / 256), dim3(256), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
-                           h->d_y, h->d_GS, d_ev, mode == 3 ? h->d_nn_idx : (const int32_t*)nullptr,
-                           mode == 3 ? h->d_nn_cnt : (const int32_t*)nullptr);
+        bool chained = false;
+        if ((rc = run_mlp<NQ>(h, M, mode, N, d_xg, true, d_p, d_ev, &chained))) return rc;
+        if (!chained)
+            hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 255) / 256), dim3(256), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
+                               h->d_y, h->d_GS, d_ev, mode == 3 ? h->d_nn_idx : (const int32_t*)nullptr,
+                               mode == 3 ? h->d_nn_cnt : (const int32_t*)nullptr);
         HIPCHK(h, hipGetLastError());
     }
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[2], s));
@@ -301,7 +333,12 @@ template <int NQ>
 int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
                  double* xo, double* uo, int32_t* st, int32_t* it) {
     int rc;
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
+    if (h->timing) {
+        h->ev_cur = (h->ev_cur + 1) % smpc_handle::EV_RING;
+        h->ev_t = h->ev_sets[h->ev_cur];
+        h->timed_count++;
+        HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
+    }
     if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev))) return rc;
     // fast path: the row count of the reference's default geometry (6 capsule pairs, config.yaml:205-216) is a
     // compile-time constant of the kernel; any other geometry takes the runtime-row-count instantiation
@@ -316,7 +353,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     }
     const int tiles = (int)ev_tiles((size_t)B * (h->N + 1));
     unsigned long long* wstat = nullptr;
-    if (h->timing) {
+    if (h->timing == 1) {      // (timing mode 2: events only, no in-kernel load-balance probe)
         if (!h->d_wstat) HIPCHK(h, hipMalloc((void**)&h->d_wstat, 4 * sizeof(unsigned long long)));
         const unsigned long long init[4] = {0ull, ~0ull, 0ull, 0ull};
         HIPCHK(h, hipMemcpyAsync(h->d_wstat, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
@@ -437,6 +474,7 @@ int rollout_workers(smpc_handle* h, int n) {
         int rc;
         if (k->N != h->N && (rc = smpc_set_horizon(k, h->N))) return fail(h, rc, "rollout worker: %s", k->err);
         k->nlayers = h->nlayers;
+        k->act = h->act;
         k->H = h->H;
         for (int l = 0; l <= SMPC_MAX_LAYERS; l++) k->dims[l] = h->dims[l];
         for (int l = 0; l < SMPC_MAX_LAYERS; l++) { k->d_Wfwd[l] = h->d_Wfwd[l]; k->d_Wbwd[l] = h->d_Wbwd[l]; k->d_bias[l] = h->d_bias[l]; }
@@ -497,7 +535,7 @@ int smpc_create(const smpc_problem_desc* desc, int device, smpc_handle** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&h->d_desc, sizeof(smpc_problem_desc));
     if (e == hipSuccess) e = hipMemcpy(h->d_desc, desc, sizeof(smpc_problem_desc), hipMemcpyHostToDevice);
-    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&h->ev_t[i]);
+    for (int i = 0; i < 5 * smpc_handle::EV_RING && e == hipSuccess; i++) e = hipEventCreate(&h->ev_sets[i / 5][i % 5]);
     if (e != hipSuccess) {
         fail(nullptr, SMPC_EHIP, "device setup failed: %s", hipGetErrorString(e));
         smpc_destroy(h);
@@ -531,7 +569,7 @@ void smpc_destroy(smpc_handle* h) {
         if (h->d_act[l]) (void)hipFree(h->d_act[l]);
         if (h->d_dg[l]) (void)hipFree(h->d_dg[l]);
     }
-    for (auto& e : h->ev_t) if (e) (void)hipEventDestroy(e);
+    for (auto& set : h->ev_sets) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     if (h->d_pol) (void)hipFree(h->d_pol);
     if (h->d_polw) (void)hipFree(h->d_polw);
     if (h->d_nn_idx) (void)hipFree(h->d_nn_idx);
@@ -580,6 +618,14 @@ int smpc_set_mlp(smpc_handle* h, int nlayers, const int32_t* dims, const float* 
     h->nlayers = nlayers;
     for (int l = 0; l <= nlayers; l++) h->dims[l] = dims[l];
     h->H = H;
+    return SMPC_OK;
+}
+
+int smpc_set_mlp_activation(smpc_handle* h, int act) {
+    if (!h) return SMPC_EINVAL;
+    if (act < SMPC_ACT_GELU_TANH || act > SMPC_ACT_SILU) return fail(h, SMPC_EINVAL, "unknown activation %d", act);
+    h->act = act;
+    for (smpc_handle* k : h->kids) k->act = act;
     return SMPC_OK;
 }
 
@@ -1144,8 +1190,9 @@ void* smpc_stream(smpc_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 int smpc_enable_timing(smpc_handle* h, int on) {
     if (!h) return SMPC_EINVAL;
-    h->timing = on ? 1 : 0;
+    h->timing = on == 2 ? 2 : (on ? 1 : 0);
     h->timed = 0;
+    h->timed_count = 0;
     return SMPC_OK;
 }
 
@@ -1173,9 +1220,35 @@ int smpc_get_qp_timing(smpc_handle* h, float* ms2) {
     return SMPC_OK;
 }
 
+int smpc_get_timing_history(smpc_handle* h, int back, float* ms6) {
+    if (!h || !ms6 || back < 0) return SMPC_EINVAL;
+    for (int i = 0; i < 6; i++) ms6[i] = 0.0f;
+    if (!h->timing || back >= smpc_handle::EV_RING || (long)back >= h->timed_count) return SMPC_OK;
+    (void)hipSetDevice(h->device);
+    hipEvent_t* ev = h->ev_sets[(h->ev_cur - back + 2 * smpc_handle::EV_RING) % smpc_handle::EV_RING];
+    if (hipEventQuery(ev[3]) != hipSuccess) { (void)hipGetLastError(); return SMPC_OK; }   // not finished yet: valid stays 0
+    HIPCHK(h, hipEventElapsedTime(&ms6[0], ev[0], ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&ms6[1], ev[1], ev[2]));
+    HIPCHK(h, hipEventElapsedTime(&ms6[2], ev[2], ev[4]));
+    HIPCHK(h, hipEventElapsedTime(&ms6[3], ev[4], ev[3]));
+    HIPCHK(h, hipEventElapsedTime(&ms6[4], ev[0], ev[3]));
+    ms6[5] = 1.0f;
+    return SMPC_OK;
+}
+
+int smpc_accumulate_stats(smpc_handle* h, int B, const int32_t* status, const int32_t* qp_iter, unsigned long long* acc3) {
+    if (!h) return SMPC_EINVAL;
+    if (B < 0 || !status || !acc3) return fail(h, SMPC_EINVAL, "bad argument");
+    if (B == 0) return SMPC_OK;
+    (void)hipSetDevice(h->device);
+    hipLaunchKernelGGL(k_accumulate_stats, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, status, qp_iter, acc3);
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
+}
+
 int smpc_get_qp_wave_stats(smpc_handle* h, double* out3) {
     if (!h || !out3) return SMPC_EINVAL;
-    if (!h->timing || !h->timed || !h->d_wstat) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
+    if (h->timing != 1 || !h->timed || !h->d_wstat) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing(1)");
     (void)hipSetDevice(h->device);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     unsigned long long w[4];

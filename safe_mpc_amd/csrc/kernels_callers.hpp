@@ -237,4 +237,27 @@ __global__ __launch_bounds__(64) void k_plant_step(const smpc_problem_desc* __re
     }
 }
 
+// sums over a batch, accumulated across calls (a closed loop's counters stay on the device):
+// acc[0] += sum of IPM iterations, acc[1] += solves with status != 0, acc[2] += solves
+__global__ __launch_bounds__(256) void k_accumulate_stats(int B, const int32_t* __restrict__ status, const int32_t* __restrict__ qp_iter,
+                                                          unsigned long long* __restrict__ acc) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long it = 0, bad = 0, n = 0;
+    if (b < B) {
+        it = qp_iter ? (unsigned long long)max(qp_iter[b], 0) : 0ull;
+        bad = status[b] != 0;
+        n = 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        it += __shfl_xor(it, o);
+        bad += __shfl_xor(bad, o);
+        n += __shfl_xor(n, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&acc[0], it);
+        atomicAdd(&acc[1], bad);
+        atomicAdd(&acc[2], n);
+    }
+}
+
 }  // namespace smpc

@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "device_model.hpp"
 
 namespace smpc {
@@ -29,7 +31,18 @@ __device__ __forceinline__ float gelu_tanh_f(float a, float* dg) {
     return 0.5f * a * (1.0f + th);
 }
 
-enum { EPI_BIAS_GELU = 0, EPI_MUL = 1, EPI_PLAIN = 2 };
+// the activations the reference's parser offers (parser.py:95-102): value and derivative, fp32
+__device__ __forceinline__ float act_f(int act, float a, float* dg) {
+    switch (act) {
+    case SMPC_ACT_RELU: *dg = a > 0.0f ? 1.0f : 0.0f; return a > 0.0f ? a : 0.0f;
+    case SMPC_ACT_ELU: { const float e = expf(a); *dg = a > 0.0f ? 1.0f : e; return a > 0.0f ? a : e - 1.0f; }     // alpha = 1 (torch default)
+    case SMPC_ACT_TANH: { const float t = tanhf(a); *dg = 1.0f - t * t; return t; }
+    case SMPC_ACT_SILU: { const float sg = 1.0f / (1.0f + expf(-a)); *dg = sg * (1.0f + a * (1.0f - sg)); return a * sg; }
+    default: return gelu_tanh_f(a, dg);
+    }
+}
+
+enum { EPI_BIAS_GELU = 0, EPI_MUL = 1, EPI_PLAIN = 2 };   // (EPI_BIAS_GELU: bias + the configured activation)
 
 // C[M x N] = A[M x K] * Bm[K x N]  (row-major, M % 32 == 0, N % 64 == 0, K % 8 == 0)
 //   EPI_BIAS_GELU: out1 = gelu(acc + bias[n]), out2 = gelu'(acc + bias[n])
@@ -39,7 +52,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const float* __restrict__ A,
                                                   const float* __restrict__ Bm, const float* __restrict__ bias,
                                                   const float* __restrict__ aux, float* __restrict__ out1,
-                                                  float* __restrict__ out2, const int32_t* __restrict__ m_live) {
+                                                  float* __restrict__ out2, const int32_t* __restrict__ m_live, int act) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m0 = (blockIdx.x * 4 + wave) * 32;
     const int n0 = blockIdx.y * 64;
@@ -97,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const flo
             const size_t o = (size_t)row * N + col;
             if (EPI == EPI_BIAS_GELU) {
                 float dg;
-                out1[o] = gelu_tanh_f(a + bias[col], &dg);
+                out1[o] = act_f(act, a + bias[col], &dg);
                 out2[o] = dg;
             } else if (EPI == EPI_MUL) {
                 out1[o] = a * aux[o];
@@ -116,7 +129,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f32_tiled(int M, int N, int K, const float* __restrict__ A,
                                                         const float* __restrict__ Bm, const float* __restrict__ bias,
                                                         const float* __restrict__ aux, float* __restrict__ out1,
-                                                        float* __restrict__ out2, const int32_t* __restrict__ m_live) {
+                                                        float* __restrict__ out2, const int32_t* __restrict__ m_live, int act) {
     constexpr int TM = 128, TN = 128, TK = 16, AS = TK + 1, BS = TN + 32;   // row strides: conflict-free column / row reads
     __shared__ float As[2][TM * AS];
     __shared__ __attribute__((aligned(16))) float Bs[2][TK * BS];
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_tiled(int M, int N, int K, con
                 const size_t o = (size_t)row * N + col;
                 if (EPI == EPI_BIAS_GELU) {
                     float dg;
-                    out1[o] = gelu_tanh_f(v + bias[col], &dg);
+                    out1[o] = act_f(act, v + bias[col], &dg);
                     out2[o] = dg;
                 } else if (EPI == EPI_MUL) {
                     out1[o] = v * aux[o];
@@ -298,6 +311,235 @@ __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N
         if (i < nd) {
             o[(SMPC_EV_OFF(nn_grad) + i) * EV_TILE] = kap * (double)gs[i] / D->nn_std[i];
             o[(SMPC_EV_OFF(nn_grad) + NQ + i) * EV_TILE] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
+        }
+    }
+}
+
+// =========================================================================================================================
+// k_mlp_fused: the WHOLE network pass for small row counts (the terminal safe-set row: M = B rows) in one kernel -- features,
+// three hidden layers forward, output, three layers backward, input gradient, chain rule -- instead of nine launches whose
+// activations make a round trip through L2 between layers (188 us at M = 4096, 7 % of the fp32 MFMA peak: launch latency).
+// A 256-thread block owns 16 rows.  Activations live in two LDS buffers (ping-pong); the activation derivatives stay in the
+// registers of the wavefront that produced them, in the accumulator layout the backward product's epilogue needs them in.
+// v_mfma_f32_16x16x4_f32: wave w owns the 64 columns 64 w .. 64 w + 63 of every 256-wide layer as four 16-column tiles taken
+// with stride 4 (tile t = columns 64 w + 4 j + t), so that one 16-byte load per lane fetches the B operands of all four tiles
+// (16 lanes x 16 B = 256 contiguous bytes of a weight row) and one 16-byte LDS write stores a lane's four outputs.
+// Weights stream from L2 (1 MB per block).  H = 256, three hidden layers (the reference's NeuralNetwork, safe_set.py:26-43).
+struct MlpWeights {
+    const float* wf[SMPC_MAX_LAYERS];     // forward operands W^T [K][N] (layer 0: K padded to MLP_KPAD)
+    const float* wb[SMPC_MAX_LAYERS];     // backward operands W [out][in] (layer 0: in padded to MLP_NPAD)
+    const float* bias[SMPC_MAX_LAYERS];
+};
+constexpr int MLPF_ROWS = 16, MLPF_H = 256, MLPF_LD = MLPF_H + 4;
+
+template <int NQ, bool BWD>
+__global__ __launch_bounds__(256) void k_mlp_fused(const smpc_problem_desc* __restrict__ D, int M, int N, int mode, int act,
+                                                   MlpWeights Wt, const double* __restrict__ xg, const double* __restrict__ p,
+                                                   const int32_t* __restrict__ idx, const int32_t* __restrict__ m_live,
+                                                   float* __restrict__ y_out, double* __restrict__ ev_out) {
+    constexpr int H = MLPF_H, LD = MLPF_LD, R = MLPF_ROWS;
+    __shared__ __attribute__((aligned(16))) float bufA[R * LD];
+    __shared__ __attribute__((aligned(16))) float bufB[R * LD];
+    __shared__ __attribute__((aligned(16))) float sfeat[R * MLP_KPAD];
+    __shared__ float sy[R];
+    __shared__ float sgs[4 * R * 16];
+    const int t = threadIdx.x, w = t >> 6, lane = t & 63, j = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * R;
+    const int live = m_live ? *m_live : M;
+    if (m0 >= live) return;                                  // (uniform: before the first barrier)
+    // ---- features (safe_set.py:82-87), one thread per row; rows past the live count are zero
+    if (t < R) {
+        const int m = m0 + t;
+        float* sf = sfeat + t * MLP_KPAD;
+#pragma unroll
+        for (int i = 0; i < MLP_KPAD; i++) sf[i] = 0.0f;
+        if (m < live) {
+            const double* x = xg + nn_row_to_node(mode, N, m, idx) * (2 * NQ);
+            const int nd = D->nn_dof;
+            double v[NQ], vn2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                v[i] = i < nd ? x[NQ + i] + (i == 0 ? D->nn_eps : 0.0) : 0.0;
+                vn2 += v[i] * v[i];
+            }
+            const double inv = 1.0 / sqrt(vn2);
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+                if (i < nd) {
+                    sf[i] = (float)((x[i] - D->nn_mean[i]) / D->nn_std[i]);
+                    sf[nd + i] = (float)(v[i] * inv);
+                }
+        }
+    }
+    __syncthreads();
+    const int c0 = 64 * w + 4 * j;                           // this lane's four columns c0 .. c0 + 3 (one per tile)
+    f32x4 acc[4];
+    float dg[3][4][4];                                       // [hidden layer][tile][row register]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) acc[tt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    // one 16-deep K chunk: 4 MFMA steps x 4 tiles.  Step r pairs A[.][16 c + 4 kq + r] with B[16 c + 4 kq + r][.]
+    auto chunk = [&](const f32x4 av, const f32x4* bv) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r][tt], acc[tt], 0, 0, 0);
+        }
+    };
+    // acc += In[16 x K] * Bm[K x 256] over this wave's columns; In in LDS (row stride ld_in), Bm row-major with 256 columns
+    auto gemm = [&](const float* In, int ld_in, const float* __restrict__ Bm, int K) {
+        const float* arow = In + j * ld_in + 4 * kq;         // (A operand: row j, four consecutive k per lane)
+        const float* brow = Bm + (size_t)(4 * kq) * H + c0;
+        // the B operands of four chunks: one in use, three in flight (a chunk's 16 MFMAs last 512 cycles, an L2 round trip
+        // under 1 024 wavefronts streaming the same weights rather longer)
+        f32x4 bq[4][4];
+        auto bload = [&](f32x4* bv, int c) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) bv[r] = *reinterpret_cast<const f32x4*>(brow + (size_t)(16 * c + r) * H);
+        };
+        bload(bq[0], 0);
+        if (K == 16) {
+            chunk(*reinterpret_cast<const f32x4*>(arow), bq[0]);
+            return;
+        }
+        const int nch = K >> 4;                              // (a multiple of 4: K is a multiple of 64)
+        bload(bq[1], 1);
+        bload(bq[2], 2);
+        bload(bq[3], 3);
+        // (sched_barrier: left alone, the scheduler sinks every load to just before its first use -- fewer live registers, and
+        //  one load in flight instead of twelve)
+        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < nch; c += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                chunk(*reinterpret_cast<const f32x4*>(arow + 16 * (c + q)), bq[q]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + q + 4 < nch) bload(bq[q], c + q + 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // C/D map of a 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + register
+    auto store_rows = [&](float* Out, const float v[4][4]) {   // v[tile][reg] -> Out[4 kq + reg][c0 + tile]
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            *reinterpret_cast<f32x4*>(Out + (4 * kq + r) * LD + c0) = f32x4{v[0][r], v[1][r], v[2][r], v[3][r]};
+    };
+    auto forward_epilogue = [&](auto ltag, float* Out) {
+        constexpr int l = decltype(ltag)::value;
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(Wt.bias[l] + c0);
+        float v[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[tt][r] = act_f(act, acc[tt][r] + bs[tt], &dg[l][tt][r]);
+        store_rows(Out, v);
+    };
+    // ---- forward: layer 0 (K = MLP_KPAD), layers 1, 2
+    zero_acc();
+    gemm(sfeat, MLP_KPAD, Wt.wf[0], MLP_KPAD);
+    forward_epilogue(std::integral_constant<int, 0>{}, bufA);
+    __syncthreads();
+    zero_acc();
+    gemm(bufA, LD, Wt.wf[1], H);
+    forward_epilogue(std::integral_constant<int, 1>{}, bufB);
+    __syncthreads();
+    zero_acc();
+    gemm(bufB, LD, Wt.wf[2], H);
+    forward_epilogue(std::integral_constant<int, 2>{}, bufA);
+    __syncthreads();
+    // ---- output layer: y = a . w3 + b3 (16 threads per row, 16 columns each)
+    {
+        const int row = t >> 4, part = t & 15;
+        const float* a = bufA + row * LD + 16 * part;
+        const float* w3 = Wt.wb[3] + 16 * part;             // (the last layer's W is [1][H])
+        float sacc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; c++) sacc = fmaf(a[c], w3[c], sacc);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+        if (part == 0) {
+            const float yv = sacc + Wt.bias[3][0];
+            sy[row] = yv;
+            if (y_out && m0 + row < live) y_out[m0 + row] = yv;
+        }
+    }
+    if (!BWD) return;
+    __syncthreads();                                         // (every wave has read bufA)
+    // ---- backward: delta2 = w3 (.) act'(z2); delta1 = (delta2 W2) (.) act'(z1); delta0 = (delta1 W1) (.) act'(z0)
+    {
+        const f32x4 w3 = *reinterpret_cast<const f32x4*>(Wt.wb[3] + c0);
+        float v[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[tt][r] = w3[tt] * dg[2][tt][r];
+        store_rows(bufB, v);
+    }
+    __syncthreads();
+    auto backward_epilogue = [&](auto ltag, float* Out) {
+        constexpr int l = decltype(ltag)::value;
+        float v[4][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[tt][r] = acc[tt][r] * dg[l][tt][r];
+        store_rows(Out, v);
+    };
+    zero_acc();
+    gemm(bufB, LD, Wt.wb[2], H);
+    backward_epilogue(std::integral_constant<int, 1>{}, bufA);
+    __syncthreads();
+    zero_acc();
+    gemm(bufA, LD, Wt.wb[1], H);
+    backward_epilogue(std::integral_constant<int, 0>{}, bufB);
+    __syncthreads();
+    // ---- input gradient: GS[16 x 16] = delta0 [16 x 256] * W0 [256 x MLP_NPAD], columns 0..15; wave w takes k = 64 w .. 64 w + 63
+    {
+        f32x4 g = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const float* arow = bufB + j * LD + 64 * w + 4 * kq;
+        const float* bcol = Wt.wb[0] + (size_t)(64 * w + 4 * kq) * MLP_NPAD + j;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+#pragma unroll
+            for (int r = 0; r < 4; r++) g = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bcol[(size_t)(16 * c + r) * MLP_NPAD], g, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) sgs[(w * R + 4 * kq + r) * 16 + j] = g[r];
+    }
+    __syncthreads();
+    // ---- chain rule back to the state (safe_set.py:82-94) and the per-node switch (utils.py:207-210): nn_val, nn_grad
+    if (t < R && m0 + t < live) {
+        const int m = m0 + t;
+        const long node = nn_row_to_node(mode, N, m, idx);
+        const double* x = xg + node * (2 * NQ);
+        const double* pk = p + node * SMPC_NP;
+        if (pk[4] > 0.0) {                                   // (switched off: the row sits mid-bounds, (0, 0) is left)
+            double* const o = ev_node(ev_out, node);
+            const int nd = D->nn_dof;
+            float gs[MLP_KPAD];
+#pragma unroll
+            for (int i = 0; i < MLP_KPAD; i++) gs[i] = ((sgs[(0 * R + t) * 16 + i] + sgs[(1 * R + t) * 16 + i]) + sgs[(2 * R + t) * 16 + i]) + sgs[(3 * R + t) * 16 + i];
+            double v[NQ], vn2 = 0.0, gdv = 0.0;
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                v[i] = i < nd ? x[NQ + i] + (i == 0 ? D->nn_eps : 0.0) : 0.0;
+                vn2 += v[i] * v[i];
+            }
+            const double vn = sqrt(vn2);
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+                if (i < nd) gdv += (double)gs[nd + i] * v[i];
+            const double kap = (100.0 - pk[3]) / 100.0;
+            o[SMPC_EV_OFF(nn_val) * EV_TILE] = (double)sy[t] * kap - vn;
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+                if (i < nd) {
+                    o[(SMPC_EV_OFF(nn_grad) + i) * EV_TILE] = kap * (double)gs[i] / D->nn_std[i];
+                    o[(SMPC_EV_OFF(nn_grad) + NQ + i) * EV_TILE] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
+                }
         }
     }
 }

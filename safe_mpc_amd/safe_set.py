@@ -40,9 +40,12 @@ class NeuralNetwork(nn.Module):
 class SafeSetNet:
     """Weights + normalisation of the safe-set network, ready to hand to the engine."""
 
+    ACT_CODES = {'gelu': 0, 'relu': 1, 'elu': 2, 'tanh': 3, 'silu': 4}      # SMPC_ACT_* of include/smpc.h (parser.py:95-102)
+
     def __init__(self, model: NeuralNetwork, mean, std, act='gelu'):
-        if act != 'gelu':
-            raise NotImplementedError('the HIP MLP kernels implement GELU(tanh), the reference default (config.yaml:67)')
+        if act not in self.ACT_CODES:
+            raise ValueError(f'unknown activation {act!r} (parser.py:95-102 offers {sorted(self.ACT_CODES)})')
+        self.act = act
         self.model = model.float().eval()
         self.mean = np.asarray(mean, np.float64).reshape(-1)
         self.std = np.asarray(std, np.float64).reshape(-1)

@@ -85,6 +85,9 @@ class BatchedOcpSolver:
         Wp = (C.c_void_p * n)(*[w.ctypes.data for w in Ws])
         bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
         self._chk(self.L.smpc_set_mlp(self.h, n, dims.ctypes.data_as(C.POINTER(C.c_int32)), Wp, bp, 0))
+        act = getattr(net, 'act', 'gelu')
+        codes = {'gelu': 0, 'relu': 1, 'elu': 2, 'tanh': 3, 'silu': 4}                 # SMPC_ACT_* (parser.py:95-102)
+        self._chk(self.L.smpc_set_mlp_activation(self.h, codes[act]))
         self.net = net
 
     def set_horizon(self, N):
@@ -123,6 +126,7 @@ class BatchedOcpSolver:
         self._chk(self.L.smpc_sync(self.h))
 
     def enable_timing(self, on=True):
+        """True / 1: HIP events + the load-balance probe inside k_qp_ipm; 2: events only; False / 0: off"""
         self._chk(self.L.smpc_enable_timing(self.h, int(on)))
 
     def timing(self):
@@ -135,6 +139,22 @@ class BatchedOcpSolver:
         return {'time_lin': ms[0] * 1e-3, 'time_nn': ms[1] * 1e-3, 'time_qp': ms[2] * 1e-3, 'time_tot': ms[3] * 1e-3,
                 'time_qp_setup': q[0] * 1e-3, 'time_qp_ipm': q[1] * 1e-3,
                 'qp_wave_busy_mean': w[0] * 1e-6, 'qp_wave_span': w[1] * 1e-6}
+
+    def timing_history(self, back=0):
+        """per-kernel times of the solve ``back`` solves before the last one (the engine keeps 64), or None if it has not
+        finished / does not exist; never waits"""
+        ms = (C.c_float * 6)()
+        self._chk(self.L.smpc_get_timing_history(self.h, int(back), ms))
+        if ms[5] == 0.0:
+            return None
+        return {'time_lin': ms[0] * 1e-3, 'time_nn': ms[1] * 1e-3, 'time_qp_setup': ms[2] * 1e-3, 'time_qp_ipm': ms[3] * 1e-3,
+                'time_tot': ms[4] * 1e-3}
+
+    def accumulate_stats(self, status, qp_iter, acc):
+        """acc (3 x int64 on the device) += [sum of IPM iterations, failed solves, solves] -- no host round trip"""
+        with self._ordered(1):
+            self._chk(self.L.smpc_accumulate_stats(self.h, int(status.shape[0]), status.data_ptr(), qp_iter.data_ptr() if qp_iter is not None else None,
+                                                   acc.data_ptr()))
 
     # -- argument plumbing -----------------------------------------------------------------------------------------------
     def _prep(self, arrs, shapes, dtypes=None):
@@ -384,13 +404,12 @@ class BatchedOcpSolver:
                                             joints_noisy.data_ptr() if joints_noisy is not None else None,
                                             tau_noise.data_ptr() if tau_noise is not None else None))
 
-    def plant_step(self, x, u, joints_noisy=None, tau_noise=None):
-        """AdamModel.integrate (env_model.py:192-206) for B instances."""
+    def plant_step(self, x, u, joints_noisy=None, tau_noise=None, out=None):
+        """AdamModel.integrate (env_model.py:192-206) for B instances.  ``out`` (device path): (x_next, u_eff) tensors to fill."""
         B = x.shape[0]
         if _is_torch(x):
             import torch
-            xn = torch.empty_like(x)
-            ue = torch.empty_like(u)
+            xn, ue = out if out is not None else (torch.empty_like(x), torch.empty_like(u))
             jn = joints_noisy.data_ptr() if joints_noisy is not None else None
             tn = tau_noise.data_ptr() if tau_noise is not None else None
             with self._ordered(1):

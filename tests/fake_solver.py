@@ -8,7 +8,7 @@ from oracle.oracle import Oracle
 class OracleSolver:
     def __init__(self, problem, net=None, device=0):
         self.problem = problem
-        self.o = Oracle(problem, (net.weights, net.biases) if net is not None else None)
+        self.o = Oracle(problem, (net.weights, net.biases, getattr(net, "act", "gelu")) if net is not None else None)
         self.N, self.nx, self.nu, self.nq = problem.N, problem.nx, problem.nu, problem.nq
         self.scripted_status = None          # optional list of status arrays consumed by successive solves
 

@@ -1,0 +1,36 @@
+"""Multi-GPU readiness on ONE GPU: the path the driver takes on an 8-GPU node -- bench.py as a torch.distributed
+rank over RCCL, the rollout log gathered to rank 0, exactly one JSON line on stdout -- exercised with a single rank
+(SMPC_FORCE_DIST=1).  The file sorts first on purpose: bench.py must be started as a fresh child by a process that has not
+touched the GPU yet (a GPU-initialised process must never exec another program on this pool)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_runs_as_a_torch_distributed_rank_over_rccl():
+    import torch
+    from safe_mpc_amd import _lib
+    if torch.cuda.is_initialized() or _lib._lib is not None:
+        pytest.skip('needs a process that has not initialised the GPU (run the whole suite, or this file alone)')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SMPC_FORCE_DIST='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]                      # the contract: ONE JSON line (RCCL's banner goes to stderr)
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['config']['failed_instance_steps'] == 0 and 3.0 < d['config']['mean_ipm_iterations'] < 12.0
+    assert d['roofline']['bound'] == 'hbm' and d['roofline']['achieved'] > 0 and d['cpu_baseline'] is None
+    assert d['roofline']['kernel_ms_in_loop']['launches_sampled'] > 0

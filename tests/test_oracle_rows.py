@@ -97,6 +97,22 @@ def test_mlp_matches_torch(setup):
     assert sum(w.size for w in net.weights) + sum(b.size for b in net.biases) == 135169
 
 
+@pytest.mark.parametrize('act', ['relu', 'elu', 'tanh', 'silu', 'gelu'])
+def test_mlp_activations_match_torch(act):
+    """parser.py:95-102: every activation the reference's parser offers, oracle (fp32 loops) vs torch autograd."""
+    from conftest import make_problem
+    from oracle.oracle import Oracle
+    par, prob, net = make_problem('st', act=act)
+    assert net.act == act
+    o = Oracle(prob, (net.weights, net.biases, net.act))
+    S = np.random.default_rng(4).uniform(-1.5, 1.5, (32, 12)).astype(np.float32)
+    y_t, g_t = net.torch_value_and_grad(S)
+    for i in range(32):
+        y, g = o.mlp(S[i])
+        assert abs(y - y_t[i]) <= 2e-5 * max(1.0, abs(y_t[i]))
+        assert np.allclose(g, g_t[i], atol=5e-6, rtol=2e-4)
+
+
 def test_nn_row_formula_and_gradient(setup):
     par, prob, net, o = setup
     rng = np.random.default_rng(3)
