@@ -250,7 +250,7 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
             return SMPC_OK;
         }
     }
-    hipLaunchKernelGGL((k_nn_features<NQ>), dim3((Mp + 255) / 256), dim3(256), 0, s, h->d_desc, M, Mp, N, mode, d_x,
+    hipLaunchKernelGGL((k_nn_features<NQ>), dim3((Mp + 63) / 64), dim3(64), 0, s, h->d_desc, M, Mp, N, mode, d_x,
                        h->d_S, idx, live);
     const dim3 blk(256), grd(Mp / 128, H / 64);
     hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, MLP_KPAD, h->d_S, h->d_Wfwd[0], h->d_bias[0],
@@ -293,7 +293,7 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
     const int N = h->N;
     hipStream_t s = h->stream;
     const long n1 = (long)B * (N + 1);
-    hipLaunchKernelGGL((k_node_geometry<NQ>), dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, s, h->d_desc, B, N, d_xg,
+    hipLaunchKernelGGL((k_node_geometry<NQ>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg,
                        d_p, d_ev);
     hipLaunchKernelGGL((k_node_torque<NQ>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg, d_ug,
                        d_ev);
@@ -308,12 +308,12 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
         if (mode == 3) {
             if ((rc = ensure_nn_idx(h, (size_t)M))) return rc;
             HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
-            hipLaunchKernelGGL(k_nn_compact, dim3((M + 255) / 256), dim3(256), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
+            hipLaunchKernelGGL(k_nn_compact, dim3((M + 63) / 64), dim3(64), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
         }
         bool chained = false;
         if ((rc = run_mlp<NQ>(h, M, mode, N, d_xg, true, d_p, d_ev, &chained))) return rc;
         if (!chained)
-            hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 255) / 256), dim3(256), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
+            hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 63) / 64), dim3(64), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
                                h->d_y, h->d_GS, d_ev, mode == 3 ? h->d_nn_idx : (const int32_t*)nullptr,
                                mode == 3 ? h->d_nn_cnt : (const int32_t*)nullptr);
         HIPCHK(h, hipGetLastError());
@@ -424,7 +424,10 @@ int check_nodes_dev(smpc_handle* h, int B, int n_nodes, const double* d_x, doubl
     double* d_rlb = d_max + nx;
     double* d_rub = d_rlb + SMPC_MAX_ROWS;
     HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)d_ok, 1, (size_t)B, s));   // verdicts start at "ok", stream-ordered
-    const dim3 grd((unsigned)((M + 127) / 128)), blk(128);
+    // (one wavefront per block throughout the small kernels: a multi-wave block needs room on several SIMDs of ONE CU at the
+    //  same moment, and next to resident QP wavefronts -- 256 registers each, two fill a SIMD -- it waited for that up to a
+    //  millisecond: k_policy_post, six blocks of four waves, averaged 131 us in the three-stream loop; rocprofv3, round 3)
+    const dim3 grd((unsigned)((M + 63) / 64)), blk(64);
     switch (nq) {
     case 5: hipLaunchKernelGGL((k_check_nodes<5>), grd, blk, 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok, coll_nodes); break;
     case 6: hipLaunchKernelGGL((k_check_nodes<6>), grd, blk, 0, s, h->d_desc, B, n_nodes, d_x, d_min, d_max, tol_x, d_rlb, d_rub, d_ok, coll_nodes); break;
@@ -437,7 +440,7 @@ int check_nodes_dev(smpc_handle* h, int B, int n_nodes, const double* d_x, doubl
         // nodes' own positions of d_nn, the rest of d_nn is left as it is
         DISPATCH_NQ(h, (run_mlp<NQ_>(h, (int)M, nn_listed ? 3 : 0, 0, d_x, false)));
         if (rc) return rc;
-        const dim3 g2((unsigned)((M + 255) / 256)), b2(256);
+        const dim3 g2((unsigned)((M + 63) / 64)), b2(64);
         const int32_t* li = nn_listed ? h->d_nn_idx : nullptr;
         const int32_t* lc = nn_listed ? h->d_nn_cnt : nullptr;
         switch (nq) {
@@ -765,7 +768,8 @@ int smpc_guess_correction(smpc_handle* h, int B, double* xg, const double* ug, i
         HIPCHK(h, hipMemcpyAsync(duw, ug, sizeof(double) * B * N * nq, hipMemcpyHostToDevice, s));
         du = duw;
     }
-    hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 255) / 256), dim3(256), 0, s, B, N, nq, h->desc.dt, dx, du, (const uint8_t*)nullptr);
+    hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 63) / 64), dim3(64), 0, s, B, N, nq, h->desc.dt, dx, du, (const uint8_t*)nullptr,
+                       (int32_t*)nullptr);
     HIPCHK(h, hipGetLastError());
     if (!on_device) {
         HIPCHK(h, hipMemcpyAsync(xg, dx, sizeof(double) * B * (N + 1) * nx, hipMemcpyDeviceToHost, s));
@@ -783,7 +787,7 @@ int smpc_provide_control(smpc_handle* h, int B, const int32_t* accept, const dou
     hipStream_t s = h->stream;
     const size_t nX = (size_t)B * (N + 1) * nx, nU = (size_t)B * N * nq;
     if (on_device) {
-        hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, accept, x_temp,
+        hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 63) / 64), dim3(64), 0, s, B, N, nq, accept, x_temp,
                            u_temp, xg, ug, u_apply, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const double*)nullptr);
         HIPCHK(h, hipGetLastError());
         return SMPC_OK;
@@ -801,7 +805,7 @@ int smpc_provide_control(smpc_handle* h, int B, const int32_t* accept, const dou
     HIPCHK(h, hipMemcpyAsync(d_xg, xg, sizeof(double) * nX, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_ug, ug, sizeof(double) * nU, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(d_acc, accept, sizeof(int32_t) * B, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, d_acc, d_xt, d_ut,
+    hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 63) / 64), dim3(64), 0, s, B, N, nq, d_acc, d_xt, d_ut,
                        d_xg, d_ug, d_ua, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (const double*)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(xg, d_xg, sizeof(double) * nX, hipMemcpyDeviceToHost, s));
@@ -997,7 +1001,7 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
             int32_t *d_fails = w->d_pol, *d_accept = w->d_pol + n;
             if ((rc = smpc_guess_correction(w, n, xg_w, ug_w, 1))) break;
             if ((rc = smpc_solve_batch(w, n, xt, xg_w, ug_w, p_w, w->d_xo, w->d_uo, st_w, it_w, 1))) break;
-            hipLaunchKernelGGL(k_accept, dim3((n + 255) / 256), dim3(256), 0, w->stream, n, st_w, d_fails, d_accept);
+            hipLaunchKernelGGL(k_accept, dim3((n + 63) / 64), dim3(64), 0, w->stream, n, st_w, d_fails, d_accept);
             if ((rc = smpc_provide_control(w, n, d_accept, w->d_xo, w->d_uo, xg_w, ug_w, ut, 1))) break;
             rc = smpc_plant_step(w, n, xt, ut, dj ? dj + (size_t)lo * nq : nullptr,
                                  dnoise ? dnoise + (size_t)t * su + (size_t)lo * nq : nullptr, xt + sx, nullptr, 1);
@@ -1057,11 +1061,10 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
     int32_t* d_acc = d_safe + (size_t)B * (N + 1);
     uint8_t* d_act = (uint8_t*)(d_acc + B);
     if (kind != SMPC_POLICY_NAIVE && (rc = upload_check_bounds(h, par->x_min, par->x_max, par->row_lb_chk, par->row_ub_chk))) return rc;
-    HIPCHK(h, hipMemsetAsync(any_abort, 0, sizeof(int32_t), s));
-    // guessCorrection (not RealReceding, controller.py:524-565)
+    // guessCorrection (not RealReceding, controller.py:524-565); the launch also resets *any_abort
     if (kind != SMPC_POLICY_REAL_RECEDING)
-        hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 255) / 256), dim3(256), 0, s, B, N, nq, h->desc.dt, st->x_guess,
-                           st->u_guess, stepping);
+        hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 63) / 64), dim3(64), 0, s, B, N, nq, h->desc.dt, st->x_guess,
+                           st->u_guess, stepping, any_abort);
     if (receding) {
         if (kind == SMPC_POLICY_REAL_RECEDING) {
             const size_t n = (size_t)B * (N + 1) * nx;
@@ -1076,8 +1079,9 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
             }
             h->inst_B = B;
         }
-        hipLaunchKernelGGL(k_policy_pre, dim3((unsigned)(((size_t)B * (N + 1) + 255) / 256)), dim3(256), 0, s, B, N, nx, kind,
-                           stepping, st->r, st->p, st->x_guess, par->stage_lo, par->stage_hi, par->tube, h->d_lo_b, h->d_hi_b);
+        hipLaunchKernelGGL(k_policy_pre, dim3((unsigned)(((size_t)B * (N + 1) + 63) / 64)), dim3(64), 0, s, B, N, nx, kind,
+                           stepping, st->r, st->p, st->x_guess, par->stage_lo, par->stage_hi, par->tube, h->d_lo_b, h->d_hi_b,
+                           kind == SMPC_POLICY_REAL_RECEDING ? any_abort : (int32_t*)nullptr);
     }
     HIPCHK(h, hipGetLastError());
     h->d_active = stepping;
@@ -1092,16 +1096,16 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
             const size_t M = (size_t)B * (N + 1);
             if ((rc = ensure_nn_idx(h, M))) return rc;
             HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
-            hipLaunchKernelGGL(k_policy_safe_list, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, B, N, par->abort_flag, stepping, st->r,
+            hipLaunchKernelGGL(k_policy_safe_list, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, B, N, par->abort_flag, stepping, st->r,
                                h->d_nn_idx, h->d_nn_cnt);
         }
         if ((rc = check_nodes_dev(h, B, N + 1, st->x_temp, par->tol_x, coll, par->alpha, par->tol_safe, d_ok, receding ? d_safe : nullptr,
                                   receding)))
             return rc;
     }
-    hipLaunchKernelGGL(k_policy_post, dim3((B + 255) / 256), dim3(256), 0, s, B, N, nx, kind, par->abort_flag, stepping, st->status,
+    hipLaunchKernelGGL(k_policy_post, dim3((B + 63) / 64), dim3(64), 0, s, B, N, nx, kind, par->abort_flag, stepping, st->status,
                        d_ok, d_safe, st->x_guess, st->fails, st->current_step, st->r, st->x_viable, d_acc, d_act, abort_out, any_abort);
-    hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 255) / 256), dim3(256), 0, s, B, N, nq, d_acc, st->x_temp, st->u_temp,
+    hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 63) / 64), dim3(64), 0, s, B, N, nq, d_acc, st->x_temp, st->u_temp,
                        st->x_guess, st->u_guess, u_out, stepping, d_act, u_other);
     HIPCHK(h, hipGetLastError());
     return SMPC_OK;
@@ -1114,7 +1118,7 @@ int smpc_loop_pre(smpc_handle* h, int B, int Nb, const smpc_loop_state* ls, cons
     if (!ls->x_cur || !ls->alive || !ls->sa || !ls->ja || !ls->x_abort || !ls->u_abort || !ls->step)
         return fail(h, SMPC_EINVAL, "loop state incomplete");
     (void)hipSetDevice(h->device);
-    hipLaunchKernelGGL(k_loop_pre, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, h->desc.nq, Nb, ls->x_cur, ls->alive, ls->sa,
+    hipLaunchKernelGGL(k_loop_pre, dim3((B + 63) / 64), dim3(64), 0, h->stream, B, h->desc.nq, Nb, ls->x_cur, ls->alive, ls->sa,
                        ls->ja, ls->x_abort, ls->u_abort, r, ls->step, ls->r_log, u_other, stepping, pending, ls->resumed);
     HIPCHK(h, hipGetLastError());
     return SMPC_OK;
@@ -1127,7 +1131,7 @@ int smpc_loop_classify_aborts(smpc_handle* h, int B, const smpc_loop_state* ls, 
     if (!ls->sa) return fail(h, SMPC_EINVAL, "loop state incomplete");
     (void)hipSetDevice(h->device);
     HIPCHK(h, hipMemsetAsync(any_event, 0, sizeof(int32_t), h->stream));
-    hipLaunchKernelGGL(k_loop_classify_aborts, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, reference_quirks, ls->resumed,
+    hipLaunchKernelGGL(k_loop_classify_aborts, dim3((B + 63) / 64), dim3(64), 0, h->stream, B, reference_quirks, ls->resumed,
                        ls->sa, abort, any_event);
     HIPCHK(h, hipGetLastError());
     return SMPC_OK;
@@ -1172,7 +1176,7 @@ int smpc_loop_post(smpc_handle* h, int B, const smpc_policy_params* par, const s
     if ((rc = smpc_plant_step(h, B, ls->x_cur, u, joints_noisy, tau_noise, d_xn, nullptr, 1))) return rc;
     // one node per instance: the model bounds widened by tol_x and the rows against their check bounds = checkStateConstraints
     if ((rc = check_nodes_dev(h, B, 1, d_xn, par->tol_x, 1, 0.0, 0.0, d_okn, nullptr))) return rc;
-    hipLaunchKernelGGL(k_loop_post, dim3((B + 255) / 256), dim3(256), 0, s, B, nq, u, d_xn, d_okn, ls->step, ls->x_log, ls->u_log,
+    hipLaunchKernelGGL(k_loop_post, dim3((B + 63) / 64), dim3(64), 0, s, B, nq, u, d_xn, d_okn, ls->step, ls->x_log, ls->u_log,
                        ls->alive, ls->collided, ls->last_x, ls->last_u, ls->x_cur);
     hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(1), 0, s, ls->step);
     HIPCHK(h, hipGetLastError());
@@ -1241,7 +1245,7 @@ int smpc_accumulate_stats(smpc_handle* h, int B, const int32_t* status, const in
     if (B < 0 || !status || !acc3) return fail(h, SMPC_EINVAL, "bad argument");
     if (B == 0) return SMPC_OK;
     (void)hipSetDevice(h->device);
-    hipLaunchKernelGGL(k_accumulate_stats, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, status, qp_iter, acc3);
+    hipLaunchKernelGGL(k_accumulate_stats, dim3((B + 63) / 64), dim3(64), 0, h->stream, B, status, qp_iter, acc3);
     HIPCHK(h, hipGetLastError());
     return SMPC_OK;
 }

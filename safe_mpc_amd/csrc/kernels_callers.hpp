@@ -7,9 +7,12 @@ namespace smpc {
 
 // guessCorrection (controller.py:226-231): one thread per (instance, joint), sequential in k.  `mask` (or null): instances
 // with mask[b] == 0 are left alone (the policy layer: instances that do not step their controller this time).
+// zero_flag (may be null): one int32 this launch resets -- smpc_policy_step's any_abort, which a later kernel of the same step
+// raises with atomics (a hipMemsetAsync would be one more launch in a chain of short ones)
 __global__ void k_guess_correction(int B, int N, int nq, double dt, double* __restrict__ xg,
-                                   const double* __restrict__ ug, const uint8_t* __restrict__ mask) {
+                                   const double* __restrict__ ug, const uint8_t* __restrict__ mask, int32_t* __restrict__ zero_flag) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && zero_flag) *zero_flag = 0;
     if (t >= (long)B * nq) return;
     const long b = t / nq;
     if (mask && !mask[b]) return;

@@ -13,8 +13,9 @@ namespace smpc {
 __global__ void k_policy_pre(int B, int N, int nx, int kind, const uint8_t* __restrict__ stepping,
                              const int64_t* __restrict__ r_all, double* __restrict__ p, const double* __restrict__ xg,
                              const double* __restrict__ lo_st, const double* __restrict__ hi_st, double tube,
-                             double* __restrict__ lo_b, double* __restrict__ hi_b) {
+                             double* __restrict__ lo_b, double* __restrict__ hi_b, int32_t* __restrict__ zero_flag) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && zero_flag) *zero_flag = 0;       // (RealReceding has no guessCorrection launch to do this)
     if (t >= (long)B * (N + 1)) return;
     const long b = t / (N + 1);
     const int k = (int)(t - b * (N + 1));
