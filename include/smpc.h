@@ -120,6 +120,14 @@ typedef struct {
                                 * (controller.py:77-79; removed for noisy runs, :69-73).  x_0 is pinned, so they are
                                 * constants of the QP: a violated one makes the QP infeasible and the instance reports
                                 * SMPC_STATUS_QP_FAILURE (the iterate is still returned, as acados does) */
+    int32_t qp_stall_iters;    /* > 0: the IPM gives up (SMPC_STATUS_QP_FAILURE, the iterate is still returned) after this many
+                                * CONSECUTIVE iterations whose step length stayed below 1/2.  0 = off: an infeasible QP then runs
+                                * until its step length underflows (40-90 iterations: what RealReceding's +-1e-3 tubes,
+                                * controller.py:531-532, produce in about 1 % of its solves).  A stall is not a proof of
+                                * infeasibility -- a feasible, degenerate QP can crawl for 20 iterations before it converges
+                                * (tests/golden/c4_degenerate_start.npz) -- hence an option with a generous default where it is
+                                * switched on (24 for 'real_receding', problem.py) and none elsewhere */
+    int32_t reserved_i0;
     double dt;                 /* config.yaml:7 */
     double Q, R;               /* config.yaml:35,39 */
     double cost_scale_stage;   /* factor on the cost Q|ee-ref|^2 + R|u|^2 whose derivatives smpc_node_eval reports: acados

@@ -487,9 +487,10 @@ struct Stage {
 struct QpOpts {
     int max_iter;
     double tol, tol_res, mu0;   /* complementarity / linear-residual exit tolerances */
+    int stall_iters;            /* > 0: give up after this many consecutive iterations with a step length below 1/2 */
 };
 
-/* returns 0 converged, 2 max-iter, 3 min-step, 4 breakdown (non-PD pivot / NaN) */
+/* returns 0 converged, 2 max-iter, 3 min-step, 4 breakdown (non-PD pivot / NaN), 5 stalled (QpOpts::stall_iters) */
 int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double* dx0, const QpOpts& o, int* iters,
            double* res_out) {
     const int nq = nu;
@@ -801,6 +802,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
     };
 
     double mu = mu_now();
+    int stall = 0;
     for (it = 0; it < o.max_iter; it++) {
         if (mu <= o.tol && rho * R0 <= o.tol_res) { status = 0; break; }
         if (!factorize()) { status = 4; break; }
@@ -855,6 +857,8 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         }
         rho *= (1.0 - alpha);
         mu = mu_now();
+        stall = alpha < 0.5 ? stall + 1 : 0;
+        if (o.stall_iters > 0 && stall >= o.stall_iters) { status = 5; it++; break; }
         if (std::getenv("SMPC_ORACLE_TRACE"))
             std::fprintf(stderr, "it %3d a_aff %.3e sigma %.3e alpha %.3e mu %.3e rho*R0 %.3e  blocked by stage %d row %d (tl %.2e ll %.2e tu %.2e lu %.2e)\n",
                          it, a_aff, sigma, alpha, mu, rho * R0, blk_k, blk_r, S[blk_k].tl[blk_r], S[blk_k].ll[blk_r], S[blk_k].tu[blk_r], S[blk_k].lu[blk_r]);
@@ -1123,7 +1127,7 @@ int orc_solve_batch(void* h, int B, const double* x0, const double* xg, const do
     Oracle* o = (Oracle*)h;
     const smpc_problem_desc& D = o->D;
     int N = o->N, nq = D.nq, nx = 2 * nq, nu = nq;
-    QpOpts qo{D.qp_max_iter, D.qp_tol, D.qp_tol_res > 0.0 ? D.qp_tol_res : D.qp_tol, D.qp_mu0};
+    QpOpts qo{D.qp_max_iter, D.qp_tol, D.qp_tol_res > 0.0 ? D.qp_tol_res : D.qp_tol, D.qp_mu0, D.qp_stall_iters};
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; b++) {
         const double* xb = xg + (size_t)b * (N + 1) * nx;

@@ -736,6 +736,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const double tol = D->qp_tol;
     const double tol_r = D->qp_tol_res > 0.0 ? D->qp_tol_res : D->qp_tol;
     const int max_iter = D->qp_max_iter;
+    const int stall_max = D->qp_stall_iters;     // > 0: give up after this many consecutive iterations with alpha < 1/2 (smpc.h)
+    int stall = 0;
     bool broke = false;
     double *Pc = sIMG + O_PA, *Pn = sIMG + O_PB2;    // P_{k+1} (in use) / P_k (being built)
     double *pvc = sIMG + O_PVA, *pvn = sIMG + O_PVB;  // costate vectors, same ping-pong
@@ -1288,6 +1290,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         // sum(lambda t) is a quadratic in the step length: the new complementarity is known before the step is applied
         mu = (mu * (double)m_comp + alpha * S1c + alpha * alpha * S2c) * inv_m;
         if (!(mu == mu)) { st_code = 4; pending = false; break; }
+        stall = alpha < 0.5 ? stall + 1 : 0;
+        if (stall_max > 0 && stall >= stall_max) { st_code = 5; it++; break; }    // (the step just computed is still applied)
     }
     if (it == max_iter && st_code == 2 && mu <= tol && rho_lin * R0 <= tol_r) st_code = 0;
 

@@ -46,6 +46,7 @@ class ProblemDesc(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('nq', C.c_int32), ('N', C.c_int32), ('n_points', C.c_int32),
                 ('n_rows', C.c_int32), ('ee_point', C.c_int32), ('cost_kind', C.c_int32), ('hessian', C.c_int32),
                 ('nn_mode', C.c_int32), ('nn_dof', C.c_int32), ('qp_max_iter', C.c_int32), ('rows_at_node0', C.c_int32),
+                ('qp_stall_iters', C.c_int32), ('reserved_i0', C.c_int32),
                 ('dt', C.c_double), ('Q', C.c_double), ('R', C.c_double), ('cost_scale_stage', C.c_double),
                 ('cost_scale_term', C.c_double), ('lm_stage', C.c_double), ('lm_term', C.c_double),
                 ('nn_eps', C.c_double), ('nn_soft_e', C.c_double), ('nn_soft_run', C.c_double),
@@ -259,6 +260,8 @@ class OcpProblem:
             else int(bool(rows_at_node0))
         d.qp_max_iter = params.qp_max_iter
         d.qp_tol, d.qp_mu0 = float(getattr(params, 'qp_tol', 1e-8)), 1.0
+        # stall exit of the IPM (include/smpc.h): on for RealReceding, whose tubes make ~1 % of its QPs infeasible
+        d.qp_stall_iters = int(getattr(params, 'qp_stall_iters', 24 if controller == 'real_receding' else 0))
         d.qp_tol_res = float(getattr(params, 'qp_tol_res', 0.0))     # 0: same as qp_tol
         self.desc = d
 

@@ -28,7 +28,7 @@ def test_struct_mirrors_match_header_sizes():
     assert C.sizeof(Point) == 8 + 24
     assert C.sizeof(Row) == 6 * 4 + 10 * 8
     assert C.sizeof(NodeEval) == 8 * (7 + 49 * 3 + 3 + 7 + 49 + 12 + 84 + 1 + 14)
-    assert C.sizeof(ProblemDesc) == 12 * 4 + 13 * 8 + 3 * 8 + 2 * 7 * 8 + 4 * 14 * 8 + 7 * C.sizeof(Joint) + \
+    assert C.sizeof(ProblemDesc) == 14 * 4 + 13 * 8 + 3 * 8 + 2 * 7 * 8 + 4 * 14 * 8 + 7 * C.sizeof(Joint) + \
         12 * C.sizeof(Point) + 12 * C.sizeof(Row)
 
 

@@ -181,3 +181,8 @@ def test_c4_degenerate_start_on_a_collision_bound():
     assert sa[0] == 0 and sb[0] == 0
     assert ia[0] <= 40 and abs(int(ia[0]) - int(ib[0])) <= 2
     assert np.abs(ua - ub).max() < 1e-4 * (1 + np.abs(ub).max())
+    # ... and with the IPM's stall exit switched on at RealReceding's default the degenerate but FEASIBLE start still converges
+    par2, prob2, net2 = make_problem_fr7(N=40)
+    prob2.desc.qp_stall_iters = 24
+    xc, uc, sc, ic = BatchedOcpSolver(prob2, net2).solve(x0, xg, ug, p)
+    assert sc[0] == 0 and ic[0] == ia[0] and np.array_equal(uc, ua)

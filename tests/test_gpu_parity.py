@@ -232,6 +232,28 @@ def test_instance_bounds_parity():
     assert np.array_equal(ua1, ua0)
 
 
+def test_stall_exit_parity_on_infeasible_tubes():
+    """qp_stall_iters -- engine and oracle give up on the same infeasible RealReceding QPs at the same
+    iteration (QP failure, iterate still returned), and the option leaves feasible solves alone."""
+    from test_oracle_qp import _unreachable_tube
+    N = 12
+    par, prob, net = make_problem('real_receding', N=N)
+    s, o = _solver(prob, net), _oracle(prob, net)
+    x0 = sample_instances(prob, 24, seed=4)
+    xg, ug, p = constant_guess(prob, x0)
+    lo, hi = _unreachable_tube(prob, x0, N)
+    lo[::2], hi[::2] = prob.x_min, prob.x_max                     # every other instance keeps the model bounds: feasible
+    lo[::2, N], hi[::2, N] = prob.lbx_e, prob.ubx_e
+    s.set_instance_bounds(lo, hi); o.set_instance_bounds(lo, hi)
+    xa, ua, sa, ia = s.solve(x0, xg, ug, p)
+    xb, ub, sb, ib = o.solve_batch(x0, xg, ug, p)
+    assert np.array_equal(sa, sb) and np.all(sb[1::2] == 4) and np.all(sb[::2] == 0)
+    assert np.abs(ia.astype(int) - ib.astype(int)).max() <= 2 and ia[1::2].max() <= 32
+    ok = sb == 0
+    assert np.abs(ua[ok] - ub[ok]).max() < 1e-4 * (1 + np.abs(ub[ok]).max())
+    s.set_instance_bounds(None, None)
+
+
 @pytest.mark.parametrize('nq,B,drop_rows', [(6, 1, 0), (6, 33, 0), (5, 17, 0), (6, 9, 2)])
 def test_kernel_instantiations_and_odd_batches(nq, B, drop_rows):
     """k_qp_ipm pairs two instances per wavefront: odd batches leave a lone half-wave; nq = 5 (the reference's default

@@ -178,3 +178,37 @@ def test_rows_at_node0_report_qp_failure():
     o_n = Oracle(prob_n)
     assert o_n.solve_batch(x0[1:], xg[1:], ug[1:], p[1:])[2][0] == 0
     par.noise = 0.0
+
+
+def _unreachable_tube(prob, x0, N, node=3, shift=0.4):
+    """RealReceding's box at one node (controller.py:531-532), centred where the arm cannot be after `node` steps"""
+    B = len(x0)
+    lo = np.broadcast_to(prob.x_min, (B, N + 1, 12)).copy()
+    hi = np.broadcast_to(prob.x_max, (B, N + 1, 12)).copy()
+    lo[:, N], hi[:, N] = prob.lbx_e, prob.ubx_e
+    centre = x0.copy()
+    centre[:, :6] += shift * np.sign(0.5 * (prob.x_min[:6] + prob.x_max[:6]) - x0[:, :6])      # towards the middle of the joint range
+    lo[:, node], hi[:, node] = centre - 1e-3, centre + 1e-3
+    return lo, hi
+
+
+def test_stall_exit_gives_up_on_an_infeasible_tube_and_spares_feasible_solves():
+    """qp_stall_iters (include/smpc.h; 24 for 'real_receding', problem.py): an infeasible QP is abandoned with QP failure after
+    24 consecutive blocked iterations instead of 40-90; feasible solves are unaffected by the option."""
+    N = 12
+    par, prob, net = make_problem('real_receding', N=N)
+    assert prob.desc.qp_stall_iters == 24
+    par0, prob0, _ = make_problem('real_receding', N=N, qp_stall_iters=0)
+    assert prob0.desc.qp_stall_iters == 0
+    x0 = sample_instances(prob, 6, seed=4)
+    xg, ug, p = constant_guess(prob, x0)
+    o, o0 = Oracle(prob, (net.weights, net.biases)), Oracle(prob0, (net.weights, net.biases))
+    xa, ua, sa, ia = o.solve_batch(x0, xg, ug, p)
+    xb, ub, sb, ib = o0.solve_batch(x0, xg, ug, p)
+    assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(ua, ub)      # feasible: the option changes nothing
+    lo, hi = _unreachable_tube(prob, x0, N)
+    o.set_instance_bounds(lo, hi); o0.set_instance_bounds(lo, hi)
+    _, _, sa, ia = o.solve_batch(x0, xg, ug, p)
+    _, _, sb, ib = o0.solve_batch(x0, xg, ug, p)
+    assert np.all(sa == 4) and np.all(sb == 4)                      # QP failure either way (controller.py:125,158 test for it)
+    assert ia.max() <= 24 + 8 and ib.min() > ia.max()
