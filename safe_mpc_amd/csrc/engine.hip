@@ -293,10 +293,8 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
     const int N = h->N;
     hipStream_t s = h->stream;
     const long n1 = (long)B * (N + 1);
-    hipLaunchKernelGGL((k_node_geometry<NQ>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg,
+    hipLaunchKernelGGL((k_node_linearise<NQ>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg, d_ug,
                        d_p, d_ev);
-    hipLaunchKernelGGL((k_node_torque<NQ>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg, d_ug,
-                       d_ev);
     HIPCHK(h, hipGetLastError());
     if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
     if (h->desc.nn_mode != SMPC_NN_NONE) {

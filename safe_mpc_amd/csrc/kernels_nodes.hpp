@@ -10,10 +10,8 @@ namespace smpc {
 
 // ---- K1: geometry + cost, one thread per (b, k), k = 0..N ---------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* __restrict__ D, int B, int N,
-                                                       const double* __restrict__ xg, const double* __restrict__ p,
-                                                       double* __restrict__ out) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void node_geometry(const smpc_problem_desc* __restrict__ D, int B, int N, const double* __restrict__ xg,
+                                              const double* __restrict__ p, double* __restrict__ out, const long t) {
     if (t >= (long)B * (N + 1)) return;
     constexpr int NX = 2 * NQ;
     const double* x = xg + t * NX;
@@ -129,10 +127,8 @@ __global__ __launch_bounds__(128) void k_node_geometry(const smpc_problem_desc* 
 // so that EV_TILE neighbouring lanes always belong to one tile; the terminal nodes (no torque row) idle.  (Round 1 ran 3 NQ
 // single-tangent dual-number passes per node in 3 NQ threads: 0.48 ms per 4096 x 30 nodes.)
 template <int NQ>
-__global__ __launch_bounds__(64) void k_node_torque(const smpc_problem_desc* __restrict__ D, int B, int N,
-                                                    const double* __restrict__ xg, const double* __restrict__ ug,
-                                                    double* __restrict__ out) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void node_torque(const smpc_problem_desc* __restrict__ D, int B, int N, const double* __restrict__ xg,
+                                            const double* __restrict__ ug, double* __restrict__ out, const long t) {
     if (t >= (long)B * (N + 1)) return;
     constexpr int NX = 2 * NQ;
     const long b = t / (N + 1);
@@ -150,6 +146,18 @@ __global__ __launch_bounds__(64) void k_node_torque(const smpc_problem_desc* __r
     }
     rd::rnea_with_derivatives<NQ>(D->joints, D->gravity, q, qd, qdd, o + SMPC_EV_OFF(tau) * EV_TILE, o + SMPC_EV_OFF(M) * EV_TILE,
                                   o + SMPC_EV_OFF(dtau_dq) * EV_TILE, o + SMPC_EV_OFF(dtau_dv) * EV_TILE, (long)EV_TILE);
+}
+
+// The linearisation kernel: geometry + cost, then torque row and Jacobians, one thread per node, ONE launch.  As two kernels
+// (rounds 1-2) each of them waited for SIMD room of its own in the three-stream closed loop -- a wavefront of either needs a
+// SIMD that holds no QP wavefront (310 / 512 registers per lane) -- about 0.13 ms per wait against 0.04 / 0.05 ms of work.
+template <int NQ>
+__global__ __launch_bounds__(64) void k_node_linearise(const smpc_problem_desc* __restrict__ D, int B, int N,
+                                                       const double* __restrict__ xg, const double* __restrict__ ug,
+                                                       const double* __restrict__ p, double* __restrict__ out) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    node_geometry<NQ>(D, B, N, xg, p, out, t);
+    node_torque<NQ>(D, B, N, xg, ug, out, t);
 }
 
 // smpc_eval_nodes: the interleaved tiles back into plain records, one thread per (node, element)
