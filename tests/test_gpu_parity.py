@@ -254,15 +254,27 @@ def test_stall_exit_parity_on_infeasible_tubes():
     s.set_instance_bounds(None, None)
 
 
-@pytest.mark.parametrize('nq,B,drop_rows', [(6, 1, 0), (6, 33, 0), (5, 17, 0), (6, 9, 2)])
+@pytest.mark.parametrize('nq,B,drop_rows', [(6, 1, 0), (6, 33, 0), (5, 17, 0), (6, 9, 2), (6, 12, 6), (6, 11, -6), (7, 6, -4)])
 def test_kernel_instantiations_and_odd_batches(nq, B, drop_rows):
     """k_qp_ipm pairs two instances per wavefront: odd batches leave a lone half-wave; nq = 5 (the reference's default
-    n_dofs, config.yaml:10) and a row count other than the specialised 6 take other template instantiations."""
+    n_dofs, config.yaml:10) and a row count other than the specialised 6 take other template instantiations.  The extremes:
+    no collision rows at all, SMPC_MAX_ROWS = 12 of them, and (nq = 7, 10 rows) the stage that fills all 32 row lanes."""
     par, prob, net = make_problem('st', 'ext', N=12, nq=nq)
-    if drop_rows:
-        prob.desc.n_rows -= drop_rows          # the last capsule pairs go: the runtime-row-count kernel
-    s, o = _solver(prob, net), _oracle(prob, net)
     x0 = sample_instances(prob, B, seed=5, vel_scale=0.1)
+    if drop_rows > 0:
+        prob.desc.n_rows -= drop_rows          # the last capsule pairs go: the runtime-row-count kernel
+    elif drop_rows < 0:
+        # more rows: the same capsule pairs again with a laxer lower bound (distinct rows, mostly inactive)
+        n0 = prob.desc.n_rows
+        for r in range(-drop_rows):
+            src = prob.desc.rows[r % n0]
+            dst = prob.desc.rows[n0 + r]
+            for f, _ in type(src)._fields_:
+                setattr(dst, f, getattr(src, f))
+            dst.lb = 0.6 * src.lb
+        prob.desc.n_rows = n0 - drop_rows
+        assert 3 * nq + prob.desc.n_rows + 1 <= 32
+    s, o = _solver(prob, net), _oracle(prob, net)
     xg, ug, p = constant_guess(prob, x0)
     xa, ua, sa, ia = s.solve(x0, xg, ug, p)
     xb, ub, sb, ib = o.solve_batch(x0, xg, ug, p)
