@@ -16,7 +16,7 @@
 //                 a1 = C^T e1, a2 = C^T e2 (the corrector gradient is gh0 + sigma mu a1 + cw a2)
 //   B2  backward: costate recursion of the corrector with the stored factors (touches neither rows nor Jacobian)
 //   F2  forward : corrector roll-out, ratio test, z+ and c.z+ of every row (B1 rebuilds the row steps from them)
-// Data movement (v8; the git history and DESIGN.md section 4 have v1-v7 and what each taught):
+// Data movement (v8, stores reorganised in v9, factor block packed in v10; the git history and DESIGN.md section 4 have v1-v7 and what each taught):
 //   * what a single lane owns -- the bounds, slacks and multipliers of "its" constraint row, its column of [G | rho | I] --
 //     goes from the HBM workspace straight into that lane's registers, re-loaded for the next stage right after its
 //     last use in this one;
@@ -66,7 +66,12 @@ template <int NQ> struct QpLayout {
     static constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ;
     static constexpr int NZP = qp_even_c(NZ), NQP = qp_even_c(NQ), WS2 = qp_even_c(NX + 1);
     static constexpr int LC0 = WS2;                    // factor rows: first column of L^-1
-    static constexpr int KS = qp_even_c(LC0 + NQ);     // row stride of the factor block = lanes that own a column
+    static constexpr int KS = qp_even_c(LC0 + NQ);     // lanes that own a column of [G | rho | . | I] in the factorisation sweep
+    // The factor block as stored, column by column, nothing padded: the NX + 1 columns of [W | w] (NQ doubles each), then the
+    // columns of L^-1 from their diagonal entry down (column j at w_coff(j), NQ - j doubles) -- 100 doubles at NQ = 6 where the
+    // rectangular NQ x KS image of v1-v9 took 120, and this block is written once and read three times per iteration.
+    static constexpr int WR = NX + 1, LOFF = NQ * WR, NWP = qp_even_c(LOFF + NQ * (NQ + 1) / 2);
+    __host__ __device__ static constexpr int w_coff(int j) { return LOFF + j * NQ - j * (j - 1) / 2; }
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
@@ -94,7 +99,7 @@ template <int NQ> struct QpLayout {
         nC = NQ * NZP + MR * NQP + NX;
         oC = o; o += qp_al8(nC);
         oIMG = o; o += qp_al8(nIMG);
-        oW = o; o += qp_al8(NQ * KS);      // factor rows [W_i | w_i | . | row i of L^-1]
+        oW = o; o += qp_al8(NWP);         // factor block: columns of [W | w], then the packed columns of L^-1
         oSL = o; o += 16;                  // [soft weight, b != 0, ., . | setup partials: R0, sum lambda t, count, node-0 rows
         oPART = oSL + 4;                   //  infeasible | the corrector's w (B2 -> F2; one whole 64-byte sector)]
         oWC = oSL + 8;
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     int32_t* __restrict__ last_iter, unsigned long long* __restrict__ wstat, const uint8_t* __restrict__ active) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
-                  LC0 = LyT::LC0, KS = LyT::KS;
+                  LC0 = LyT::LC0, KS = LyT::KS, NWP = LyT::NWP;
     // load-balance probe (smpc_get_qp_wave_stats): two reads of the constant 100 MHz clock per half-wave; the first one is
     // parked in LDS (the kernel has no register to spare)
     __shared__ unsigned long long s_tbegin[2];
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int CST_MAX = NRC_MAX * NZP;                                       // row-major image of the general rows in LDS
     constexpr int NC_MAX = NQ * NZP + MR_MAX * NQP + NX, CST_PF = (NC_MAX / 2 + 31) / 32;   // ... fetched without its zeros
     static_assert(NQ * NZP / 2 >= 32, "the first piece of every lane lies in the torque rows");
-    constexpr int W_N2 = NQ * KS / 2, WST_PF = (W_N2 + 31) / 32;                 // ... and the factor block
+    constexpr int W_N2 = NWP / 2, WST_PF = (W_N2 + 31) / 32;                 // ... and the factor block
     // (staged in LDS by the other sweeps, in the buffers that only the factorisation sweep uses)
 #ifdef QP_PROFILE
     unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -626,8 +631,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sG = sIMG + O_G;
     double* const sWT = sIMG + O_WT;
     double* const sHXX = sIMG + O_HXX;
-    static_assert(CST_MAX + 2 * NQ * KS <= O_PVA - O_TD, "staging area of the forward sweeps");
-    static_assert(NQ * KS <= NZ * NQP + NQ * MRP_MAX, "B1 lays the factor block out in the scaled-rows buffers before storing it");
+    static_assert(CST_MAX + 2 * NWP <= O_PVA - O_TD, "staging area of the forward sweeps");
+    static_assert(NWP + NQ <= NZ * NQP + NQ * MRP_MAX, "B1 lays the factor block out in the scaled-rows buffers before storing it");
     double* const sCst = sIMG + O_TD;                      // forward sweeps only: general rows ...
     double* const sWstA = sIMG + O_TD + CST_MAX;           // ... and the factor block, double-buffered (B2: single)
     double* const sPB = sIMG + O_PB;
@@ -662,6 +667,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const int hl_px = hz >= NU ? hz - NU : 0;                        // state component of the lanes NU..
     const int hc = hl < KS ? hl : KS - 1;                            // column of [G | rho | . | I]
     const bool soft_lane = (hr == rNN);
+    // where this lane's column of the factor block starts in the stored image (entry i of the column at wbase + i): the
+    // lanes 0..NX own the columns of [W | w]; lane LC0 + j owns column j of L^-1, whose entries above the diagonal are zeros
+    // that land on the tail of the columns before it and are overwritten there by the (later) stores of those entries; the
+    // lanes in between write zeros behind the block (and its pad entry, if it has one)
+    const int wbase = hc <= NX ? hc * NQ
+                               : ((hc < LC0 || hc - LC0 >= NQ) ? NWP - (LyT::LOFF + NQ * (NQ + 1) / 2) % 2
+                                                                : LyT::w_coff(hc - LC0) - (hc - LC0));
+    const int lbase = LyT::w_coff(hl_u) - hl_u;                  // L^-1[j][hl_u] (j >= hl_u) sits at lbase + j
 
     // Base of stage k's record.  Opaque to the optimiser on purpose: otherwise loop-invariant code motion precomputes one
     // 64-bit pointer per (block, lane role) pair -- some forty register pairs that live across the whole kernel and spill.
@@ -931,7 +944,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         // the block goes out as whole 16-byte pieces (WST_PF store instructions instead of NQ narrow ones: this
                         // stream pays per store): laid out in the scaled-rows buffer, which is dead since the assembly
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) sTD[i * KS + hc] = col[i];
+                        for (int i = 0; i < NQ; i++) sTD[wbase + i] = col[i];   // (in this order: see wbase)
                     }
                     lds_fence();
                     {
@@ -1008,7 +1021,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             // (ping-pong buffers as offsets, not pointers: an offset can go through an optimisation barrier without the LDS
             //  address space being lost)
             int o_xb = O_XB, o_xn = O_XB + NX;
-            int o_wc = O_TD + CST_MAX, o_wn = O_TD + CST_MAX + NQ * KS;    // factor block of this stage / of the next one
+            int o_wc = O_TD + CST_MAX, o_wn = O_TD + CST_MAX + NWP;    // factor block of this stage / of the next one
             dbl2 Cs[CST_PF], Ws[WST_PF];
             // the rows of a stage (bounds, slacks, multipliers, c.z pair, (b_i, soft weight)) in TWO register sets: the loads of
             // stage k + 1 go out at the top of stage k, a whole stage before their use.  (With one set they could only be
@@ -1098,17 +1111,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 load_r(nxt, kn);
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
-                    const double* wr_ = wc_ + hl_u * KS;
-                    double a = CORR ? cur.wc : wr_[NX];
+                    const double* wr_ = wc_ + hl_u;          // row hl_u of [W | w]: one entry per column
+                    double a = CORR ? cur.wc : wr_[NX * NQ];
 #pragma unroll
-                    for (int j = 0; j < NX; j++) a = fma(wr_[j], xb[j], a);
+                    for (int j = 0; j < NX; j++) a = fma(wr_[j * NQ], xb[j], a);
                     if (hl < NQ) sRho[hl] = a;
                 }
                 lds_fence();
                 {
                     double a = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) a = fma(wc_[j * KS + LC0 + hl_u], sRho[j], a);
+                    for (int j = 0; j < NQ; j++) a = fma(hl_u <= j ? wc_[lbase + j] : 0.0, sRho[j], a);   // L^-T rho
                     if (hl < NQ) sZU[hl] = last ? 0.0 : -a;
                 }
                 lds_fence();
@@ -1238,7 +1251,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     {
                         double v = 0.0;
 #pragma unroll
-                        for (int j = 0; j < NQ; j++) v = fma(sWstA[hl_u * KS + LC0 + j], sRho[j], v);
+                        for (int j = 0; j < NQ; j++)   // L^-1 rho: row hl_u, entries j <= hl_u
+                            v = fma(j <= hl_u ? sWstA[LyT::w_coff(j) - j + hl_u] : 0.0, sRho[j], v);
                         if (hl < NQ) sWv[hl] = v;
                         // the corrector's w: one 64-byte sector of its own (inside the factor block it was NQ separate
                         // read-modify-writes); lanes NQ.. hold the last entry again and fill the sector
@@ -1248,7 +1262,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     if (k > 0 && hz >= NU) {
                         double v = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
 #pragma unroll
-                        for (int t = 0; t < NQ; t++) v = fma(-sWstA[t * KS + hl_px], sWv[t], v);
+                        for (int t = 0; t < NQ; t++) v = fma(-sWstA[hl_px * NQ + t], sWv[t], v);
                         pvn[hl_px] = v;
                     }
                 }
