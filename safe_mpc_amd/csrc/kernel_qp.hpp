@@ -814,27 +814,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 load_b1(k > 0 ? k - 1 : 0);
                 // -- P b, and the rows scaled by their barrier weights
                 {
-                    double a = 0.0;
-                    if (bflag) {
-#pragma unroll
-                        for (int jx = 0; jx < NX; jx++) a = fma(Pc[hl_x * NX + jx], sB[jx], a);
-                    }
+                    // (whole 16-byte reads: as twelve scalar ones the compiler, short of registers, waits for each in turn)
+                    const double a = bflag ? pdot(Pc + hl_x * NX, sB, NX / 2) : 0.0;
                     sPB[hl_x] = a;   // (reaches the corrector's backward sweep folded into the stored gradient, below)
                 }
                 // (fixed trip counts with clamped indices instead of data-dependent loop bounds: the passes of one loop are
                 //  independent, and only a fully unrolled loop lets the scheduler overlap their LDS round trips)
+                if constexpr (NQ % 2 == 0) {
+                    // Two entries per lane and pass (a row of Tt has NQP = NQ entries, a row of Gt MRP: a pair never straddles
+                    // two rows, and rT0, rC0 are even), and every read before the first write: the compiler cannot tell the
+                    // arrays apart, so a write between two passes' reads makes each pass a round trip through LDS of its own.
+                    constexpr int TD_P = (NZ * NQP / 2 + 31) / 32, GD_P = (NQ * MRP_MAX / 2 + 31) / 32;
+                    const dbl2* tt2 = reinterpret_cast<const dbl2*>(sTT);
+                    const dbl2* gt2 = reinterpret_cast<const dbl2*>(sGT);
+                    dbl2 ta[TD_P], td[TD_P], ga[GD_P], gd[GD_P];
 #pragma unroll
-                for (int t = 0; t < (NZ * NQP + 31) / 32; t++) {
-                    const int el = min(hl + 32 * t, NZ * NQP - 1);
-                    const int r = el % NQP;
-                    sTD[el] = sTT[el] * sD[rT0 + (r < NQ ? r : 0)];   // pad entries of Tt are zero
-                }
+                    for (int t = 0; t < TD_P; t++) {
+                        const int e2 = min(hl + 32 * t, NZ * NQP / 2 - 1);
+                        ta[t] = tt2[e2];
+                        td[t] = reinterpret_cast<const dbl2*>(sD + rT0)[e2 % (NQP / 2)];
+                    }
 #pragma unroll
-                for (int t = 0; t < (NQ * MRP_MAX + 31) / 32; t++) {
-                    const int el = hl + 32 * t;
-                    if (el < NQ * MRP) {
-                        const int r = el % MRP;
-                        sGD[el] = sGT[el] * sD[rC0 + (r < MR ? r : 0)];
+                    for (int t = 0; t < GD_P; t++) {
+                        const int e2 = max(min(hl + 32 * t, NQ * (MRP >> 1) - 1), 0);   // (no collision rows: nothing is written)
+                        const int r2 = e2 % max(MRP >> 1, 1);
+                        ga[t] = gt2[e2];
+                        gd[t] = reinterpret_cast<const dbl2*>(sD + rC0)[r2];
+                        if (2 * r2 + 1 >= MR) gd[t].y = 0.0;   // (the pad column of Gt; its neighbour in D is the safe-set row)
+                    }
+#pragma unroll
+                    for (int t = 0; t < TD_P; t++) reinterpret_cast<dbl2*>(sTD)[min(hl + 32 * t, NZ * NQP / 2 - 1)] = ta[t] * td[t];
+#pragma unroll
+                    for (int t = 0; t < GD_P; t++)
+                        if (MR > 0) reinterpret_cast<dbl2*>(sGD)[max(min(hl + 32 * t, NQ * (MRP >> 1) - 1), 0)] = ga[t] * gd[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < (NZ * NQP + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NZ * NQP - 1);
+                        const int r = el % NQP;
+                        sTD[el] = sTT[el] * sD[rT0 + (r < NQ ? r : 0)];   // pad entries of Tt are zero
+                    }
+#pragma unroll
+                    for (int t = 0; t < (NQ * MRP_MAX + 31) / 32; t++) {
+                        const int el = hl + 32 * t;
+                        if (el < NQ * MRP) {
+                            const int r = el % MRP;
+                            sGD[el] = sGT[el] * sD[rC0 + (r < MR ? r : 0)];
+                        }
                     }
                 }
                 lds_fence();
@@ -845,8 +871,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int t = 0; t < (NTRI_U + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NTRI_U - 1);   // (lanes past the end repeat the last element)
                         const int i = triUi[el], j = triUj[el];
+                        const double huu = sSC[0];
                         double a = pdot(sTT + i * NQP, sTD + j * NQP, NQP / 2);
-                        if (i == j) a += sSC[0];
+                        a += i == j ? huu : 0.0;
                         // B^T P B = c^2 P11 + c dt (P12 + P21) + dt^2 P22
                         a += cB * cB * Pc[i * NX + j] + cB * dt * (Pc[i * NX + NQ + j] + Pc[(NQ + i) * NX + j]) +
                              dt * dt * Pc[(NQ + i) * NX + NQ + j];
@@ -874,13 +901,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NTRI_X - 1);
                         const int ix = triXi[el], jx = triXj[el];
+                        // (the diagonal's extras are read with everything else and selected: behind a branch each of them is
+                        //  a round trip through LDS of its own)
+                        const double dii = sD[ix], lmv = sSC[1];
                         double a = pdot(sTT + (NU + ix) * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                         a = fma(sGN[ix] * dnn, sGN[jx], a);
                         if (jx < NQ) a += sHQQ[ix * NQ + jx] + pdot(sGT + ix * MRP, sGD + jx * MRP, MRP >> 1);
-                        if (ix == jx) {
-                            a += sD[ix];
-                            if (ix >= NQ) a += sSC[1];
-                        }
+                        a += ix == jx ? dii + (ix >= NQ ? lmv : 0.0) : 0.0;
                         if (last) { Pn[ix * NX + jx] = a; Pn[jx * NX + ix] = a; }
                         else sHXX[ix * NX + jx] = a;
                     }
