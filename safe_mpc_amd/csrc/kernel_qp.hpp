@@ -886,11 +886,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         const int i = el / NX, jx = el - i * NX;
                         double a = pdot(sTT + i * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                         // B^T P A: left block c P11 + dt P21 ; right block dt (c P11 + dt P21) + c P12 + dt P22
-                        if (jx < NQ) a += cB * Pc[i * NX + jx] + dt * Pc[(NQ + i) * NX + jx];
-                        else {
-                            const int jj = jx - NQ;
-                            a += dt * (cB * Pc[i * NX + jj] + dt * Pc[(NQ + i) * NX + jj]) + cB * Pc[i * NX + NQ + jj] +
-                                 dt * Pc[(NQ + i) * NX + NQ + jj];
+                        // (all four entries read whatever the block, as in the P update below)
+                        {
+                            const bool right = jx >= NQ;
+                            const int jj = right ? jx - NQ : jx;
+                            const double q00 = Pc[i * NX + jj], q10 = Pc[(NQ + i) * NX + jj], q01 = Pc[i * NX + jx],
+                                         q11 = Pc[(NQ + i) * NX + jx];
+                            const double left = cB * q00 + dt * q10;
+                            a += right ? dt * left + cB * q01 + dt * q11 : left;
                         }
                         sG[i * WS2 + jx] = a;
                     }
@@ -906,43 +909,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         const double dii = sD[ix], lmv = sSC[1];
                         double a = pdot(sTT + (NU + ix) * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                         a = fma(sGN[ix] * dnn, sGN[jx], a);
-                        if (jx < NQ) a += sHQQ[ix * NQ + jx] + pdot(sGT + ix * MRP, sGD + jx * MRP, MRP >> 1);
+                        {
+                            const int iq = min(ix, NQ - 1), jq = min(jx, NQ - 1);   // (the q-q block: jx < NQ; read by every lane)
+                            const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
+                            a += jx < NQ ? qq : 0.0;
+                        }
                         a += ix == jx ? dii + (ix >= NQ ? lmv : 0.0) : 0.0;
                         if (last) { Pn[ix * NX + jx] = a; Pn[jx * NX + ix] = a; }
                         else sHXX[ix * NX + jx] = a;
                     }
                 }
                 // -- gradient: g + C^T e; lanes NU.. keep the x part in a register for the costate update
+                // (every operand is read by every lane and the lane's kind selects: behind branches each read was a round trip
+                //  through LDS of its own -- eight of them in this block)
                 double ghx = 0.0;
                 {
-                    double gh = sGZ[hz];
+                    const int ix = hl_px, iq = min(hl_px, NQ - 1);   // state component of the lanes NU.. (0 on the control lanes)
+                    const double g0 = sGZ[hz], eb = sE[ix], gnn = sGN[ix] * sE[rNN];
+                    double tq = 0.0, cq = 0.0;
+                    if constexpr (NQ % 2 == 0) {
+                        tq = pdot(sTT + hz * NQP, sE + rT0, NQP / 2);
+                        cq = pdot(sGT + iq * MRP, sE + rC0, MRP >> 1);   // (pad column of Gt: zero, times the safe-set row's e)
+                    } else {
 #pragma unroll
-                    for (int r = 0; r < NQ; r++) gh = fma(sTT[hz * NQP + r], sE[rT0 + r], gh);
-                    if (hz >= NU) {
-                        const int ix = hz - NU;
-                        gh += sE[ix];
-                        gh = fma(sGN[ix], sE[rNN], gh);
-                        if (ix < NQ)
-                            for (int r = 0; r < MR; r++) gh = fma(sGT[ix * MRP + r], sE[rC0 + r], gh);
+                        for (int r = 0; r < NQ; r++) tq = fma(sTT[hz * NQP + r], sE[rT0 + r], tq);
+                        for (int r = 0; r < MR; r++) cq = fma(sGT[iq * MRP + r], sE[rC0 + r], cq);
                     }
+                    const double gh = g0 + tq + (hz >= NU ? eb + gnn + (ix < NQ ? cq : 0.0) : 0.0);
                     // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one.  Its recursion needs P b only as
                     // B^T P b (controls) and A^T P b (states), both constants of the iteration: stored with the gradient, so B2
                     // loads no P b (sPB of this stage was written before the last fence; it is zero at the end stage)
-                    {
-                        double ghs = gh;
-                        if (!last) {
-                            if (hz < NU) ghs += cB * sPB[hz] + dt * sPB[NQ + hz];
-                            else ghs += hl_px < NQ ? sPB[hl_px] : dt * sPB[hl_px - NQ] + sPB[hl_px];
-                        }
-                        stnt_s(ghs, w + Ly.oGH0 + hz);
-                    }
+                    const bool ctl = hz < NU;
+                    const double pb1 = sPB[ctl ? hz : ix], pb2 = sPB[ctl ? NQ + hz : (ix >= NQ ? ix - NQ : 0)];
+                    const double fold = (ctl ? cB : 1.0) * pb1 + (ctl || ix >= NQ ? dt : 0.0) * pb2;
+                    stnt_s(last ? gh : gh + fold, w + Ly.oGH0 + hz);
                     if (last) {
                         if (hz >= NU) pvn[hz - NU] = gh;
-                    } else if (hl < NU) {
-                        // rho = gh_u + B^T (p_{k+1} + P b)
-                        sG[hl * WS2 + NX] = gh + cB * (pvc[hl] + sPB[hl]) + dt * (pvc[NQ + hl] + sPB[NQ + hl]);
                     } else {
-                        ghx = gh;
+                        // rho = gh_u + B^T (p_{k+1} + P b)  (on the control lanes pb1, pb2 are entries hl, NQ + hl of P b)
+                        const double rho = gh + cB * (pvc[hl_u] + pb1) + dt * (pvc[NQ + hl_u] + pb2);
+                        if (hl < NU) sG[hl * WS2 + NX] = rho;
+                        else ghx = gh;
                     }
                 }
                 lds_fence();
@@ -991,12 +998,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             const int el = min(hl + 32 * t, NTRI_X - 1);
                             const int i = triXi[el], j = triXj[el];
                             double a = sHXX[i * NX + j];
-                            // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]
-                            if (j < NQ) a += Pc[i * NX + j];
-                            else if (i < NQ) a += dt * Pc[i * NX + (j - NQ)] + Pc[i * NX + j];
-                            else {
-                                const int ii = i - NQ, jj = j - NQ;
-                                a += dt * dt * Pc[ii * NX + jj] + dt * (Pc[ii * NX + j] + Pc[i * NX + jj]) + Pc[i * NX + j];
+                            // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]; i <= j.  All four
+                            // entries are read whatever the block (clamped indices, zero coefficients): one round trip
+                            {
+                                const int ii = i >= NQ ? i - NQ : i, jj = j >= NQ ? j - NQ : j;
+                                const double p00 = Pc[i * NX + j], p01 = Pc[i * NX + jj], p10 = Pc[ii * NX + j], p11 = Pc[ii * NX + jj];
+                                const double cj = j >= NQ ? dt : 0.0, ci = i >= NQ ? dt : 0.0;
+                                a += p00 + cj * p01 + ci * (p10 + dt * p11);
                             }
                             a -= pdot(sWT + i * NQP, sWT + j * NQP, NQP / 2);
                             Pn[i * NX + j] = a;
