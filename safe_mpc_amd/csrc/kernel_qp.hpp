@@ -630,9 +630,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sLam = sIMG + O_LAM;
     double* const sG = sIMG + O_G;
     double* const sWT = sIMG + O_WT;
-    double* const sHXX = sIMG + O_HXX;
+    double* const sWI = sIMG + O_HXX;   // B1: the factor block as it is stored (NX * NX doubles of room)
     static_assert(CST_MAX + 2 * NWP <= O_PVA - O_TD, "staging area of the forward sweeps");
-    static_assert(NWP + NQ <= NZ * NQP + NQ * MRP_MAX, "B1 lays the factor block out in the scaled-rows buffers before storing it");
+    static_assert(NWP + NQ <= NX * NX, "B1 lays the factor block out in a buffer of its own before storing it");
     double* const sCst = sIMG + O_TD;                      // forward sweeps only: general rows ...
     double* const sWstA = sIMG + O_TD + CST_MAX;           // ... and the factor block, double-buffered (B2: single)
     double* const sPB = sIMG + O_PB;
@@ -898,25 +898,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         sG[i * WS2 + jx] = a;
                     }
                 }
-                {
-                    const double dnn = sD[rNN];
+                // element (ix, jx), ix <= jx, of the x-x block of H + C^T D C.  (The diagonal's extras and the q-q block are read
+                // with everything else and selected: behind a branch each of them is a round trip through LDS of its own.)
+                auto hxx_elem = [&](int ix, int jx) -> double {
+                    const double dii = sD[ix], lmv = sSC[1], dnn = sD[rNN];
+                    double a = pdot(sTT + (NU + ix) * NQP, sTD + (NU + jx) * NQP, NQP / 2);
+                    a = fma(sGN[ix] * dnn, sGN[jx], a);
+                    const int iq = min(ix, NQ - 1), jq = min(jx, NQ - 1);   // (the q-q block: jx < NQ; read by every lane)
+                    const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
+                    a += jx < NQ ? qq : 0.0;
+                    a += ix == jx ? dii + (ix >= NQ ? lmv : 0.0) : 0.0;
+                    return a;
+                };
+                if (last) {   // P_N = the x-x block itself; at the other stages it is assembled inside the P update below
 #pragma unroll
                     for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NTRI_X - 1);
                         const int ix = triXi[el], jx = triXj[el];
-                        // (the diagonal's extras are read with everything else and selected: behind a branch each of them is
-                        //  a round trip through LDS of its own)
-                        const double dii = sD[ix], lmv = sSC[1];
-                        double a = pdot(sTT + (NU + ix) * NQP, sTD + (NU + jx) * NQP, NQP / 2);
-                        a = fma(sGN[ix] * dnn, sGN[jx], a);
-                        {
-                            const int iq = min(ix, NQ - 1), jq = min(jx, NQ - 1);   // (the q-q block: jx < NQ; read by every lane)
-                            const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
-                            a += jx < NQ ? qq : 0.0;
-                        }
-                        a += ix == jx ? dii + (ix >= NQ ? lmv : 0.0) : 0.0;
-                        if (last) { Pn[ix * NX + jx] = a; Pn[jx * NX + ix] = a; }
-                        else sHXX[ix * NX + jx] = a;
+                        const double a = hxx_elem(ix, jx);
+                        Pn[ix * NX + jx] = a;
+                        Pn[jx * NX + ix] = a;
                     }
                 }
                 // -- gradient: g + C^T e; lanes NU.. keep the x part in a register for the costate update
@@ -976,13 +977,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             if (NQP > NQ) sWT[hc * NQP + NQ] = 0.0;   // (the other sweeps stage their blocks over this buffer)
                         }
                         // the block goes out as whole 16-byte pieces (WST_PF store instructions instead of NQ narrow ones: this
-                        // stream pays per store): laid out in the scaled-rows buffer, which is dead since the assembly
+                        // stream pays per store), laid out in a buffer of its own
 #pragma unroll
-                        for (int i = 0; i < NQ; i++) sTD[wbase + i] = col[i];   // (in this order: see wbase)
+                        for (int i = 0; i < NQ; i++) sWI[wbase + i] = col[i];   // (in this order: see wbase)
                     }
                     lds_fence();
                     {
-                        const dbl2* s2 = reinterpret_cast<const dbl2*>(sTD);
+                        const dbl2* s2 = reinterpret_cast<const dbl2*>(sWI);
                         dbl2* d2 = reinterpret_cast<dbl2*>(w + Ly.oW);
 #pragma unroll
                         for (int j = 0; j < WST_PF; j++) {
@@ -992,12 +993,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     }
                     QPT(3);
                     if (k > 0) {
-                        // P_k = Hxx + A^T P A - W^T W (upper triangle, mirrored into the other buffer) and p_k
+                        // P_k = Hxx + A^T P A - W^T W (upper triangle, mirrored into the other buffer) and p_k.  The x-x block of
+                        // H + C^T D C is assembled here, element by element, not in a pass of its own before the factorisation
+                        // (which needs only the u-u and u-x blocks): three passes, their index look-ups and a buffer fewer
 #pragma unroll
                         for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
                             const int el = min(hl + 32 * t, NTRI_X - 1);
                             const int i = triXi[el], j = triXj[el];
-                            double a = sHXX[i * NX + j];
+                            double a = hxx_elem(i, j);
                             // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]; i <= j.  All four
                             // entries are read whatever the block (clamped indices, zero coefficients): one round trip
                             {
@@ -1010,12 +1013,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                             Pn[i * NX + j] = a;
                             Pn[j * NX + i] = a;
                         }
-                        if (hl >= NU && hl < NZ) {
-                            const int i = hl - NU;
-                            // p_k = gh_x + A^T (p_{k+1} + P b) - W^T w
-                            double v = ghx + (i < NQ ? pvc[i] + sPB[i] : dt * (pvc[i - NQ] + sPB[i - NQ]) + pvc[i] + sPB[i]);
+                        {
+                            // p_k = gh_x + A^T (p_{k+1} + P b) - W^T w  (every lane reads, the state lanes write)
+                            const int i = hl_px, i2 = i >= NQ ? i - NQ : 0;
+                            const double q1 = pvc[i] + sPB[i], q2 = pvc[i2] + sPB[i2];
+                            double v = ghx + q1 + (i >= NQ ? dt * q2 : 0.0);
                             v -= pdot(sWT + i * NQP, sWT + NX * NQP, NQP / 2);
-                            pvn[i] = v;
+                            if (hl >= NU && hl < NZ) pvn[i] = v;
                         }
                     }
                 }
