@@ -708,17 +708,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         }
         return ok;
     };
-    // sum_r a[r] b[r] over one padded row pair (pads are zero)
+    // sum_r a[r] b[r] over one padded row pair (pads are zero).  Two accumulators: a lone wavefront pays the full latency of
+    // every dependent FMA, and one chain over all terms is twice as long as it has to be.
     auto pdot = [&](const double* a, const double* bb, int n2) -> double {
         const dbl2* a2 = reinterpret_cast<const dbl2*>(a);
         const dbl2* b2 = reinterpret_cast<const dbl2*>(bb);
-        double s = 0.0;
+        double s0 = 0.0, s1 = 0.0;
         for (int h = 0; h < n2; h++) {
             const dbl2 x = a2[h], y = b2[h];
-            s = fma(x.x, y.x, s);
-            s = fma(x.y, y.y, s);
+            s0 = fma(x.x, y.x, s0);
+            s1 = fma(x.y, y.y, s1);
         }
-        return s;
+        return s0 + s1;
     };
 
     // ---- initial residual norm and complementarity from the setup partials -----------------------------------------------
@@ -1151,9 +1152,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 // u = -L^-T (W x + w): one lane per control, two lane-parallel products with an LDS hand-off in between
                 {
                     const double* wr_ = wc_ + hl_u;          // row hl_u of [W | w]: one entry per column
-                    double a = CORR ? cur.wc : wr_[NX * NQ];
+                    // (q and v halves in accumulators of their own: this chain is on the path from one stage's state to the next)
+                    double a = CORR ? cur.wc : wr_[NX * NQ], a_v = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NX; j++) a = fma(wr_[j * NQ], xb[j], a);
+                    for (int j = 0; j < NQ; j++) {
+                        a = fma(wr_[j * NQ], xb[j], a);
+                        a_v = fma(wr_[(NQ + j) * NQ], xb[NQ + j], a_v);
+                    }
+                    a += a_v;
                     if (hl < NQ) sRho[hl] = a;
                 }
                 lds_fence();
@@ -1174,11 +1180,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 // rows: c.z for the trial point, directions, ratio test
                 {
                     const double* cr = sCst + hl_c * NZP;
-                    double a = 0.0;
+                    double a = 0.0, a_q = 0.0, a_v = 0.0;   // (three chains of NQ terms instead of one of 3 NQ)
 #pragma unroll
-                    for (int c = 0; c < NU; c++) a = fma(cr[c], sZU[c], a);
-#pragma unroll
-                    for (int c = 0; c < NX; c++) a = fma(cr[NU + c], xb[c], a);
+                    for (int c = 0; c < NQ; c++) {
+                        a = fma(cr[c], sZU[c], a);
+                        a_q = fma(cr[NU + c], xb[c], a_q);
+                        a_v = fma(cr[NU + NQ + c], xb[NQ + c], a_v);
+                    }
+                    a += a_q + a_v;
                     const double cz = hr < NX ? xb[hl_x] : a;
                     const QpRow rs{cur.r0.x, cur.r0.y, cur.r1.x, cur.r1.y, cur.r2.x, cur.r2.y};
                     const double wsoft = cur.wsoft;
