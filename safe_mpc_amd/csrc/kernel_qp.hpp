@@ -647,11 +647,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         triUi[e] = (unsigned char)i;
         triUj[e] = (unsigned char)(i + rem);
     }
+    // upper triangle of the x-x block, the q-q corner (j < NQ) first: those NTRI_U <= 32 elements then all sit in the first pass
+    // of the loops over it, and the other passes skip what only the corner needs (cost Hessian, collision rows)
+    static_assert(NTRI_U <= 32, "the q-q corner fits the first pass");
     for (int e = hl; e < NTRI_X; e += 32) {
-        int i = 0, rem = e;
-        while (rem >= NX - i) { rem -= NX - i; i++; }
+        int i = 0, j;
+        if (e < NTRI_U) {
+            int rem = e;
+            while (rem >= NQ - i) { rem -= NQ - i; i++; }
+            j = i + rem;
+        } else {
+            int rem = e - NTRI_U;
+            while (rem >= (i < NQ ? NQ : NX - i)) { rem -= (i < NQ ? NQ : NX - i); i++; }
+            j = (i < NQ ? NQ : i) + rem;
+        }
         triXi[e] = (unsigned char)i;
-        triXj[e] = (unsigned char)(i + rem);
+        triXj[e] = (unsigned char)j;
     }
 
     const double* xb0 = xg + (size_t)b * (N + 1) * NX;
@@ -901,13 +912,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 }
                 // element (ix, jx), ix <= jx, of the x-x block of H + C^T D C.  (The diagonal's extras and the q-q block are read
                 // with everything else and selected: behind a branch each of them is a round trip through LDS of its own.)
-                auto hxx_elem = [&](int ix, int jx) -> double {
+                auto hxx_elem = [&](int ix, int jx, bool corner_pass) -> double {
                     const double dii = sD[ix], lmv = sSC[1], dnn = sD[rNN];
                     double a = pdot(sTT + (NU + ix) * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                     a = fma(sGN[ix] * dnn, sGN[jx], a);
-                    const int iq = min(ix, NQ - 1), jq = min(jx, NQ - 1);   // (the q-q block: jx < NQ; read by every lane)
-                    const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
-                    a += jx < NQ ? qq : 0.0;
+                    if (corner_pass) {   // (compile-time per pass: the index table puts the whole q-q corner into the first one)
+                        const int iq = min(ix, NQ - 1), jq = min(jx, NQ - 1);   // (read by every lane of the pass, selected)
+                        const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
+                        a += jx < NQ ? qq : 0.0;
+                    }
                     a += ix == jx ? dii + (ix >= NQ ? lmv : 0.0) : 0.0;
                     return a;
                 };
@@ -916,7 +929,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NTRI_X - 1);
                         const int ix = triXi[el], jx = triXj[el];
-                        const double a = hxx_elem(ix, jx);
+                        const double a = hxx_elem(ix, jx, 32 * t < NTRI_U);
                         Pn[ix * NX + jx] = a;
                         Pn[jx * NX + ix] = a;
                     }
@@ -1001,7 +1014,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
                             const int el = min(hl + 32 * t, NTRI_X - 1);
                             const int i = triXi[el], j = triXj[el];
-                            double a = hxx_elem(i, j);
+                            double a = hxx_elem(i, j, 32 * t < NTRI_U);
                             // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]; i <= j.  All four
                             // entries are read whatever the block (clamped indices, zero coefficients): one round trip
                             {
