@@ -1268,8 +1268,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
 
         // ---------------- sweep B2: costate recursion of the corrector with the stored factors -------------------------------
-        // ~100 instructions per stage: loads run THREE stages ahead (three register sets, the loop unrolled by three)
+        // ~100 instructions per stage: loads run B2D stages ahead (as many register sets, the loop unrolled by as much)
         {
+#ifndef QP_B2_DEPTH
+#define QP_B2_DEPTH 3
+#endif
+            constexpr int B2D = QP_B2_DEPTH;
             struct BSet { double gh0; dbl2 a12; dbl2 Ws[WST_PF]; };
             // the two entries of P b this lane needs: controls (i, NQ+i), states (ix, ix-NQ)
             const int ip1 = hl < NU ? hl : hl_px;
@@ -1287,7 +1291,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 constexpr bool last = decltype(last_tag)::value;
                 asm volatile("; QPMARK B2_BEGIN");
                 double* w = stage_ptr(k);
-                const int kp = k > 3 ? k - 3 : 0;
+                const int kp = k > B2D ? k - B2D : 0;
                 const double gh = S.gh0 + sigmu * S.a12.x + corr_w * S.a12.y;   // (P b is inside gh0: B1)
                 if (last) {
                     if (hz >= NU) pvn[hz - NU] = gh;
@@ -1332,20 +1336,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 QPT(9);
                 asm volatile("; QPMARK B2_END");
             };
-            BSet S0, S1b, S2b;
-            load_b(S0, N);
-            load_b(S1b, N >= 1 ? N - 1 : 0);
-            load_b(S2b, N >= 2 ? N - 2 : 0);
-            stage_b2(S0, N, std::true_type{});
+            // stage N - m uses set m % B2D
+            BSet S[B2D];
+#pragma unroll
+            for (int j = 0; j < B2D; j++) load_b(S[j], N >= j ? N - j : 0);
+            stage_b2(S[0], N, std::true_type{});
             int k = N - 1;
 #pragma unroll 1
-            for (; k - 2 >= 0; k -= 3) {
-                stage_b2(S1b, k, std::false_type{});
-                stage_b2(S2b, k - 1, std::false_type{});
-                stage_b2(S0, k - 2, std::false_type{});
+            for (; k - (B2D - 1) >= 0; k -= B2D) {
+#pragma unroll
+                for (int j = 0; j < B2D; j++) stage_b2(S[(j + 1) % B2D], k - j, std::false_type{});
             }
-            if (k >= 0) stage_b2(S1b, k, std::false_type{});
-            if (k - 1 >= 0) stage_b2(S2b, k - 1, std::false_type{});
+#pragma unroll
+            for (int j = 0; j < B2D - 1; j++)
+                if (k - j >= 0) stage_b2(S[(j + 1) % B2D], k - j, std::false_type{});
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
