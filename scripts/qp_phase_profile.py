@@ -4,7 +4,7 @@ Usage on the GPU box:  SMPC_B=4096 python scripts/qp_phase_profile.py
 """
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ['SMPC_HIP_LIB'] = os.path.join(ROOT, 'safe_mpc_amd', 'csrc', 'libsmpc_hip_prof.so')
+os.environ['SMPC_HIP_LIB'] = os.environ.get('SMPC_PROF_LIB', os.path.join(ROOT, 'safe_mpc_amd', 'csrc', 'libsmpc_hip_prof.so'))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
