@@ -1225,14 +1225,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 load_w(kk);
                 lds_fence();
                 if (!CORR) {
-                    double a1 = 0.0, a2 = 0.0;
+                    // (all reads of a half of the rows first, then its products: read by read the compiler waits for each in turn)
+                    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+                    {
+                        constexpr int RH = (NRC_MAX + 1) / 2;
+                        double cc[RH], d1[RH], d2[RH];
 #pragma unroll
-                    for (int r = 0; r < NRC_MAX; r++)
-                        if (r < NRC) {
-                            const double c = sCst[r * NZP + hz];
-                            a1 = fma(c, sD[NX + r], a1);
-                            a2 = fma(c, sE[NX + r], a2);
+                        for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+                            for (int r = 0; r < RH; r++) {
+                                const int rr_ = min(hh * RH + r, NRC_MAX - 1);
+                                cc[r] = sCst[rr_ * NZP + hz];
+                                d1[r] = sD[NX + rr_];
+                                d2[r] = sE[NX + rr_];
+                            }
+#pragma unroll
+                            for (int r = 0; r < RH; r++) {
+                                const bool on = hh * RH + r < NRC && hh * RH + r < NRC_MAX;
+                                if (hh == 0) { a1 = on ? fma(cc[r], d1[r], a1) : a1; a2 = on ? fma(cc[r], d2[r], a2) : a2; }
+                                else { b1 = on ? fma(cc[r], d1[r], b1) : b1; b2 = on ? fma(cc[r], d2[r], b2) : b2; }
+                            }
                         }
+                    }
+                    a1 += b1;
+                    a2 += b2;
                     if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
                     stnt_s(dbl2{a1, a2}, reinterpret_cast<dbl2*>(w + Ly.oA12) + hz);
                     lds_fence();   // (the next stage overwrites the staged rows)
