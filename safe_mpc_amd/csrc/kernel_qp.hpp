@@ -156,6 +156,33 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// "These values are needed HERE": an empty asm that takes loaded values as operands makes the compiler issue all their loads
+// before this point and wait for them once.  Left to itself (and short of registers) it sinks every LDS read next to its
+// use, and a lone wavefront then pays one round trip through LDS per read.
+__device__ __forceinline__ void hold(double& a, double& b, double& c, double& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ void hold(dbl2& a, dbl2& b, dbl2& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+template <int H> __device__ __forceinline__ void hold_rows2(dbl2 (&a)[H], dbl2 (&b)[H], double (&s)[5]) {
+    static_assert(H == 3 || H == 4, "NQP / 2 of the built sizes");
+    if constexpr (H == 3)
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(s[0]), "+v"(s[1]), "+v"(s[2]),
+                          "+v"(s[3]), "+v"(s[4]));
+    else
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(s[0]),
+                          "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]));
+}
+// four padded rows (H 16-byte pieces each) and nine scalars in ONE statement: loads that are operands of different asm
+// statements may be scheduled between them, and the point is a single wait
+template <int H> __device__ __forceinline__ void hold_rows4(dbl2 (&a)[H], dbl2 (&b)[H], dbl2 (&c)[H], dbl2 (&d)[H], double (&s)[9]) {
+    static_assert(H == 3 || H == 4, "NQP / 2 of the built sizes");
+    if constexpr (H == 3)
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]),
+                          "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]),
+                          "+v"(s[6]), "+v"(s[7]), "+v"(s[8]));
+    else
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]),
+                          "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(s[0]), "+v"(s[1]),
+                          "+v"(s[2]), "+v"(s[3]), "+v"(s[4]), "+v"(s[5]), "+v"(s[6]), "+v"(s[7]), "+v"(s[8]));
+}
 // reductions over the 32 lanes of one half-wave
 __device__ __forceinline__ double half_min(double v) {
 #pragma unroll
@@ -883,12 +910,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int t = 0; t < (NTRI_U + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NTRI_U - 1);   // (lanes past the end repeat the last element)
                         const int i = triUi[el], j = triUj[el];
-                        const double huu = sSC[0];
-                        double a = pdot(sTT + i * NQP, sTD + j * NQP, NQP / 2);
-                        a += i == j ? huu : 0.0;
+                        // (operands loaded, then held: one batch of reads and one wait per pass, here and in the next loop)
+                        constexpr int H = NQP / 2;
+                        dbl2 ti[H], tj[H];
+                        double sc[5];
+#pragma unroll
+                        for (int h = 0; h < H; h++) {
+                            ti[h] = reinterpret_cast<const dbl2*>(sTT + i * NQP)[h];
+                            tj[h] = reinterpret_cast<const dbl2*>(sTD + j * NQP)[h];
+                        }
+                        sc[0] = sSC[0]; sc[1] = Pc[i * NX + j]; sc[2] = Pc[i * NX + NQ + j]; sc[3] = Pc[(NQ + i) * NX + j];
+                        sc[4] = Pc[(NQ + i) * NX + NQ + j];
+                        hold_rows2<H>(ti, tj, sc);
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int h = 0; h < H; h++) { s0 = fma(ti[h].x, tj[h].x, s0); s1 = fma(ti[h].y, tj[h].y, s1); }
+                        double a = s0 + s1;
+                        a += i == j ? sc[0] : 0.0;
                         // B^T P B = c^2 P11 + c dt (P12 + P21) + dt^2 P22
-                        a += cB * cB * Pc[i * NX + j] + cB * dt * (Pc[i * NX + NQ + j] + Pc[(NQ + i) * NX + j]) +
-                             dt * dt * Pc[(NQ + i) * NX + NQ + j];
+                        a += cB * cB * sc[1] + cB * dt * (sc[2] + sc[3]) + dt * dt * sc[4];
                         sLam[i * NQ + j] = a;
                         sLam[j * NQ + i] = a;
                     }
@@ -896,16 +936,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int t = 0; t < (NQ * NX + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NQ * NX - 1);
                         const int i = el / NX, jx = el - i * NX;
-                        double a = pdot(sTT + i * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                         // B^T P A: left block c P11 + dt P21 ; right block dt (c P11 + dt P21) + c P12 + dt P22
                         // (all four entries read whatever the block, as in the P update below)
+                        constexpr int H = NQP / 2;
+                        const bool right = jx >= NQ;
+                        const int jj = right ? jx - NQ : jx;
+                        dbl2 ti[H], tj[H];
+                        double sc[5];
+#pragma unroll
+                        for (int h = 0; h < H; h++) {
+                            ti[h] = reinterpret_cast<const dbl2*>(sTT + i * NQP)[h];
+                            tj[h] = reinterpret_cast<const dbl2*>(sTD + (NU + jx) * NQP)[h];
+                        }
+                        sc[0] = Pc[i * NX + jj]; sc[1] = Pc[(NQ + i) * NX + jj]; sc[2] = Pc[i * NX + jx]; sc[3] = Pc[(NQ + i) * NX + jx];
+                        sc[4] = 0.0;
+                        hold_rows2<H>(ti, tj, sc);
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int h = 0; h < H; h++) { s0 = fma(ti[h].x, tj[h].x, s0); s1 = fma(ti[h].y, tj[h].y, s1); }
+                        double a = s0 + s1;
                         {
-                            const bool right = jx >= NQ;
-                            const int jj = right ? jx - NQ : jx;
-                            const double q00 = Pc[i * NX + jj], q10 = Pc[(NQ + i) * NX + jj], q01 = Pc[i * NX + jx],
-                                         q11 = Pc[(NQ + i) * NX + jx];
-                            const double left = cB * q00 + dt * q10;
-                            a += right ? dt * left + cB * q01 + dt * q11 : left;
+                            const double left = cB * sc[0] + dt * sc[1];
+                            a += right ? dt * left + cB * sc[2] + dt * sc[3] : left;
                         }
                         sG[i * WS2 + jx] = a;
                     }
@@ -940,7 +992,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 double ghx = 0.0;
                 {
                     const int ix = hl_px, iq = min(hl_px, NQ - 1);   // state component of the lanes NU.. (0 on the control lanes)
-                    const double g0 = sGZ[hz], eb = sE[ix], gnn = sGN[ix] * sE[rNN];
+                    const bool ctl = hz < NU;
+                    // (all scalar operands up front, in one batch with the rows below)
+                    double g0 = sGZ[hz], eb = sE[ix], gn_i = sGN[ix], e_nn = sE[rNN];
+                    double pb1 = sPB[ctl ? hz : ix], pb2 = sPB[ctl ? NQ + hz : (ix >= NQ ? ix - NQ : 0)];
+                    double pv1 = pvc[hl_u], pv2 = pvc[NQ + hl_u];
+                    hold(g0, eb, gn_i, e_nn);
+                    hold(pb1, pb2, pv1, pv2);
+                    const double gnn = gn_i * e_nn;
                     double tq = 0.0, cq = 0.0;
                     if constexpr (NQ % 2 == 0) {
                         tq = pdot(sTT + hz * NQP, sE + rT0, NQP / 2);
@@ -954,15 +1013,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one.  Its recursion needs P b only as
                     // B^T P b (controls) and A^T P b (states), both constants of the iteration: stored with the gradient, so B2
                     // loads no P b (sPB of this stage was written before the last fence; it is zero at the end stage)
-                    const bool ctl = hz < NU;
-                    const double pb1 = sPB[ctl ? hz : ix], pb2 = sPB[ctl ? NQ + hz : (ix >= NQ ? ix - NQ : 0)];
                     const double fold = (ctl ? cB : 1.0) * pb1 + (ctl || ix >= NQ ? dt : 0.0) * pb2;
                     stnt_s(last ? gh : gh + fold, w + Ly.oGH0 + hz);
                     if (last) {
                         if (hz >= NU) pvn[hz - NU] = gh;
                     } else {
                         // rho = gh_u + B^T (p_{k+1} + P b)  (on the control lanes pb1, pb2 are entries hl, NQ + hl of P b)
-                        const double rho = gh + cB * (pvc[hl_u] + pb1) + dt * (pvc[NQ + hl_u] + pb2);
+                        const double rho = gh + cB * (pv1 + pb1) + dt * (pv2 + pb2);
                         if (hl < NU) sG[hl * WS2 + NX] = rho;
                         else ghx = gh;
                     }
@@ -1014,16 +1071,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
                             const int el = min(hl + 32 * t, NTRI_X - 1);
                             const int i = triXi[el], j = triXj[el];
-                            double a = hxx_elem(i, j, 32 * t < NTRI_U);
-                            // A^T P A, blocks: [P11, dt P11 + P12; dt P11 + P21, dt^2 P11 + dt (P12 + P21) + P22]; i <= j.  All four
-                            // entries are read whatever the block (clamped indices, zero coefficients): one round trip
+                            // every operand of the element -- rows i, j of the scaled Jacobian and of W, the safe-set row's entries,
+                            // the diagonal extras, the four entries of P_{k+1} (A^T P A by blocks: [P11, dt P11 + P12; dt P11 + P21,
+                            // dt^2 P11 + dt (P12 + P21) + P22], i <= j, clamped indices and zero weights outside a block) -- is
+                            // loaded, then held: one batch of reads, one wait
+                            constexpr int H = NQP / 2;
+                            dbl2 ti[H], tj[H], wi[H], wj[H];
+                            double sc[9];
                             {
+                                const dbl2 *pti = reinterpret_cast<const dbl2*>(sTT + (NU + i) * NQP),
+                                           *ptj = reinterpret_cast<const dbl2*>(sTD + (NU + j) * NQP),
+                                           *pwi = reinterpret_cast<const dbl2*>(sWT + i * NQP), *pwj = reinterpret_cast<const dbl2*>(sWT + j * NQP);
+#pragma unroll
+                                for (int h = 0; h < H; h++) { ti[h] = pti[h]; tj[h] = ptj[h]; wi[h] = pwi[h]; wj[h] = pwj[h]; }
                                 const int ii = i >= NQ ? i - NQ : i, jj = j >= NQ ? j - NQ : j;
-                                const double p00 = Pc[i * NX + j], p01 = Pc[i * NX + jj], p10 = Pc[ii * NX + j], p11 = Pc[ii * NX + jj];
-                                const double cj = j >= NQ ? dt : 0.0, ci = i >= NQ ? dt : 0.0;
-                                a += p00 + cj * p01 + ci * (p10 + dt * p11);
+                                sc[0] = sGN[i]; sc[1] = sGN[j]; sc[2] = sD[rNN]; sc[3] = sD[i]; sc[4] = sSC[1];
+                                sc[5] = Pc[i * NX + j]; sc[6] = Pc[i * NX + jj]; sc[7] = Pc[ii * NX + j]; sc[8] = Pc[ii * NX + jj];
                             }
-                            a -= pdot(sWT + i * NQP, sWT + j * NQP, NQP / 2);
+                            hold_rows4<H>(ti, tj, wi, wj, sc);
+                            double a;
+                            {
+                                double s0 = 0.0, s1 = 0.0, w0 = 0.0, w1 = 0.0;
+#pragma unroll
+                                for (int h = 0; h < H; h++) {
+                                    s0 = fma(ti[h].x, tj[h].x, s0); s1 = fma(ti[h].y, tj[h].y, s1);
+                                    w0 = fma(wi[h].x, wj[h].x, w0); w1 = fma(wi[h].y, wj[h].y, w1);
+                                }
+                                a = (s0 + s1) - (w0 + w1);
+                            }
+                            a = fma(sc[0] * sc[2], sc[1], a);
+                            if (32 * t < NTRI_U) {   // (the q-q corner: first pass only, see the index table)
+                                const int iq = min(i, NQ - 1), jq = min(j, NQ - 1);
+                                const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
+                                a += j < NQ ? qq : 0.0;
+                            }
+                            a += i == j ? sc[3] + (i >= NQ ? sc[4] : 0.0) : 0.0;
+                            {
+                                const double cj = j >= NQ ? dt : 0.0, ci = i >= NQ ? dt : 0.0;
+                                a += sc[5] + cj * sc[6] + ci * (sc[7] + dt * sc[8]);
+                            }
                             Pn[i * NX + j] = a;
                             Pn[j * NX + i] = a;
                         }
