@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         // ~100 instructions per stage: loads run B2D stages ahead (as many register sets, the loop unrolled by as much)
         {
 #ifndef QP_B2_DEPTH
-#define QP_B2_DEPTH 3
+#define QP_B2_DEPTH 5
 #endif
             constexpr int B2D = QP_B2_DEPTH;
             struct BSet { double gh0; dbl2 a12; dbl2 Ws[WST_PF]; };
