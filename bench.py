@@ -212,6 +212,8 @@ def main():
                          'utils.py:138-166 laid out over the instances')
     ap.add_argument('--control-noise', type=float, default=0.0, help='torque noise in percent of tau_max (env_model.py:196)')
     ap.add_argument('--no-loop-timing', action='store_true', help='do not record per-kernel HIP events inside the timed loop')
+    ap.add_argument('--no-survey-window', action='store_true',
+                    help="skip the extra untimed-for-`value` pass over SURVEY 8(d)'s window (10 warm-up + 100 timed steps)")
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
                     help='weak: --batch instances per GPU; strong: --batch instances in total, split over the GPUs')
     args = ap.parse_args()
@@ -506,6 +508,37 @@ def main():
         h = lambda a: a[:nb].cpu().numpy()
         cpu = cpu_baseline(prob, net, h(xs), h(xgf), h(ugf), h(pf))
 
+    # SURVEY 8(d) / BASELINE.md section 3 quote C1 over "100 timed steps after 10 warm-up"; the closed loop gets more expensive
+    # with time (more IPM iterations per solve), so a shorter window flatters the number.  When the run's own K / W differ, the
+    # same loop is run once more over exactly that window -- from the same initial state, after everything above, outside the
+    # timed region that `value` reports -- and added to the line.
+    survey = None
+    if world == 1 and not args.no_survey_window and not args.graphs and (args.steps, args.warmup) != (100, 10):
+        for sb in subs:
+            with torch.cuda.stream(sb.stream):
+                lo, hi = sb.off, sb.off + sb.n
+                sb.ctrl.setGuess(t(xg_h[lo:hi]), t(ug_h[lo:hi]))
+                sb.ctrl.p.copy_(t(p_h[lo:hi]))
+                sb.x_sim.copy_(t(x0_h[lo:hi]))
+                if hasattr(sb.ctrl, 'fails'):
+                    sb.ctrl.fails.zero_()
+        barrier()
+        for i in range(10):
+            step(first=(i == 0))
+        for sb in subs:
+            with torch.cuda.stream(sb.stream):
+                sb.acc.zero_()
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(100):
+            step(first=False)
+        barrier()
+        el2 = time.perf_counter() - t1
+        acc2 = sum(sb.acc.cpu().numpy().astype(np.int64) for sb in subs)
+        survey = {'steps': 100, 'warmup': 10, 'ms_per_step': 1e3 * el2 / 100, 'value': B_total * 100 / el2,
+                  'mean_ipm_iterations': float(acc2[0]) / max(int(acc2[2]), 1), 'failed_instance_steps': float(acc2[1]),
+                  'note': 'the window SURVEY 8(d) quotes C1 on, run after the timed region from the same initial state'}
+
     if rank == 0:
         total = B_total * args.steps
         line = {
@@ -523,7 +556,7 @@ def main():
                        'hip_graphs': bool(subs[0].graph is not None),
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
                        'failed_instance_steps': fails},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'survey_window': survey,
         }
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + '\n').encode())
