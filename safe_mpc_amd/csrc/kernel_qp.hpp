@@ -160,7 +160,6 @@ __device__ __forceinline__ void lds_fence() {
 // before this point and wait for them once.  Left to itself (and short of registers) it sinks every LDS read next to its
 // use, and a lone wavefront then pays one round trip through LDS per read.
 __device__ __forceinline__ void hold(double& a, double& b, double& c, double& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
-__device__ __forceinline__ void hold(dbl2& a, dbl2& b, dbl2& c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
 template <int H> __device__ __forceinline__ void hold_rows2(dbl2 (&a)[H], dbl2 (&b)[H], double (&s)[5]) {
     static_assert(H == 3 || H == 4, "NQP / 2 of the built sizes");
     if constexpr (H == 3)
