@@ -10,8 +10,9 @@
 //                half-uniform and the SIMT exec mask does the rest (a converged half idles until its twin is done;
 //                longest-first dispatch pairs instances with similar iteration counts).
 // Per IPM iteration a half-wave walks the horizon four times
-//   B1  backward: apply the previous step, barrier weights, H + C^T D C, Cholesky, W = L^-1 [G | rho], L^-1, P_k,
-//                 predictor costate and gradient gh0
+//   B1  backward: apply the previous step, barrier weights, the u rows of H + C^T D C, Cholesky, W = L^-1 [G | rho], L^-1,
+//                 P_k (its x-x block of H + C^T D C assembled element by element inside the P update), predictor costate
+//                 and gradient gh0
 //   F1  forward : predictor roll-out u = -L^-T (W x + w), ratio test, centring; c.z_aff of every row and the vectors
 //                 a1 = C^T e1, a2 = C^T e2 (the corrector gradient is gh0 + sigma mu a1 + cw a2)
 //   B2  backward: costate recursion of the corrector with the stored factors (touches neither rows nor Jacobian)
@@ -36,7 +37,10 @@
 //     single conditional load otherwise turns each wait into vmcnt(0) and serialises the stage on the loads it has just
 //     issued for the next one (same effect: a loaded register nobody reads, a spill reload in a loop preheader, a
 //     pointer that went through inline asm -- see the comments at load_n, stage_ptr and before the forward loops);
-//   * prefetch depth by sweep: B1 one stage, F1/F2 one stage for rows and two for the staged blocks, B2 three stages.
+//   * prefetch depth by sweep: B1 one stage, F1/F2 one stage for rows and two for the staged blocks, B2 five stages;
+//   * LDS latency (point 6: a lone wavefront waits one round trip after the other): no branch around an
+//     LDS read (every lane reads with clamped indices and selects), no LDS write between two passes' reads, and the operands
+//     of a pass loaded into locals and "held" (hold_rows2 / hold_rows4 below) so that they go out as one batch.
 // The double integrator's A, B are never stored (env_model.py:63-67): every product with them is expanded in closed form.
 //
 // The algorithm is the one restated in oracle/smpc_oracle.cpp::qp_ipm (same initial point, Mehrotra rule, step rule and
