@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMPC_ABI_VERSION 4
+#define SMPC_ABI_VERSION 5
 
 #define SMPC_MAX_NQ 7
 #define SMPC_MAX_NX 14
@@ -121,7 +121,8 @@ typedef struct {
                                 * constants of the QP: a violated one makes the QP infeasible and the instance reports
                                 * SMPC_STATUS_QP_FAILURE (the iterate is still returned, as acados does) */
     int32_t qp_stall_iters;    /* > 0: the IPM gives up (SMPC_STATUS_QP_FAILURE, the iterate is still returned) after this many
-                                * CONSECUTIVE iterations whose step length stayed below 1/2.  0 = off: an infeasible QP then runs
+                                * CONSECUTIVE stalled iterations: step length below 1/2 AND the complementarity not halved
+                                * either (an iterate that meets the exit test is never a stall).  0 = off: an infeasible QP then runs
                                 * until its step length underflows (40-90 iterations: what RealReceding's +-1e-3 tubes,
                                 * controller.py:531-532, produce in about 1 % of its solves).  A stall is not a proof of
                                 * infeasibility -- a feasible, degenerate QP can crawl for 20 iterations before it converges
@@ -297,6 +298,12 @@ typedef struct {                    /* what a controller object holds per instan
     int64_t *fails, *current_step;  /* [B] */
     int64_t *r;                     /* [B] receding index (NULL for the policies without one) */
     int32_t *status, *qp_iter;      /* [B] of the last solve */
+    const double* traj;             /* [3][traj_len] reference trajectory of the cost (cost.traj, cost_definition.py:30-31,89), or NULL.
+                                       Not NULL: before the solve, p[b][i][0:3] = traj[:, current_step[b] + i] for every node i of the
+                                       stepping instances -- what solve() does through ocp_solver.set(i, 'p', .) at
+                                       controller.py:153-156 (column index clamped to traj_len - 1).  NULL: p[:, :, 0:3] is left as the
+                                       caller set it (the constant ee_ref of the ReachTarget costs). */
+    int64_t traj_len;
 } smpc_policy_state;
 
 /* <Controller>.step(x) for the instances with stepping[b] != 0 (NULL: all): guessCorrection, the policy's flags / bounds,

@@ -76,7 +76,8 @@ class Oracle:
             pass
 
     def set_mlp(self, weights, biases, act='gelu'):
-        code = {'gelu': 0, 'relu': 1, 'elu': 2, 'tanh': 3, 'silu': 4}[act]
+        from safe_mpc_amd.safe_set import SafeSetNet           # the one table of SMPC_ACT_* codes (include/smpc.h)
+        code = SafeSetNet.ACT_CODES[act]
         assert self.L.orc_set_mlp_activation(self.h, code) == 0
         n = len(weights)
         Ws = [np.ascontiguousarray(w, np.float32) for w in weights]

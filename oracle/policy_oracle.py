@@ -18,9 +18,11 @@ statements of the same automata, which the tests compare with this one).  All nu
 object, so the automata can be driven by scripted statuses / scripted safe-set verdicts as well as by a real solver:
 
     numerics.integrate_naively(x, u) -> x_next                       env_model.py:210-212 (the controller's own model)
-    numerics.solve(x0, x_guess, u_guess, flags, lo, hi) -> (status, x_traj, u_traj)
+    numerics.solve(x0, x_guess, u_guess, flags, lo, hi, ref=None) -> (status, x_traj, u_traj)
             flags[k]: last entry of the node parameter p (> 0: safe-set row on, utils.py:207-210)
             lo / hi : per-node state bounds [N+1][nx], or None for the formulation's own
+            ref     : per-node reference points [N+1][3] (first three entries of p, controller.py:153-156), or None for the
+                      constant ee_ref (only passed when the instance carries a trajectory)
     numerics.check_state_constraints(x_traj) -> bool                  env_model.py:170-173
     numerics.check_safe(x_node) -> bool                               safe_set.py:61-68
   driver only:
@@ -49,6 +51,7 @@ class PolicyInstance:
         self.hi = None
         self.x_viable = np.zeros(nx)
         self.last_status = 4                       # controller.py:125
+        self.traj = None                           # cost.traj [3][n_steps + 1 + N] (cost_definition.py:30-31, 89); None = constant ee_ref
         self.reset()
 
     # controller.py:233-237 (+ :362-365 for the safe-set classes, :445-447 for the receding ones)
@@ -73,7 +76,12 @@ def guess_correction(inst, numerics):
 
 def solve(inst, numerics, x0):
     """controller.py:136-167: the iterate is kept whatever the status."""
-    status, x_traj, u_traj = numerics.solve(np.array(x0, float), inst.x_guess, inst.u_guess, inst.flags, inst.lo, inst.hi)
+    if inst.traj is not None:
+        # :153-156  p_i = [cost.traj[:, current_step + i], alpha, flag_i]
+        ref = [np.array([inst.traj[c][inst.current_step + i] for c in range(3)], float) for i in range(inst.N + 1)]
+        status, x_traj, u_traj = numerics.solve(np.array(x0, float), inst.x_guess, inst.u_guess, inst.flags, inst.lo, inst.hi, ref=ref)
+    else:
+        status, x_traj, u_traj = numerics.solve(np.array(x0, float), inst.x_guess, inst.u_guess, inst.flags, inst.lo, inst.hi)
     for i in range(inst.N):
         inst.x_temp[i] = np.array(x_traj[i], float)
         inst.u_temp[i] = np.array(u_traj[i], float)

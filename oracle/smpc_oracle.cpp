@@ -856,9 +856,12 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
             }
         }
         rho *= (1.0 - alpha);
+        const double mu_before = mu;
         mu = mu_now();
-        stall = alpha < 0.5 ? stall + 1 : 0;
-        if (o.stall_iters > 0 && stall >= o.stall_iters) { status = 5; it++; break; }
+        /* a stalled iteration: a short step that did not halve the complementarity either (a degenerate but feasible QP
+         * crawls with short steps while mu still falls); an iterate that meets the exit test is never reported as stalled */
+        stall = (alpha < 0.5 && !(mu < 0.5 * mu_before)) ? stall + 1 : 0;
+        if (o.stall_iters > 0 && stall >= o.stall_iters && !(mu <= o.tol && rho * R0 <= o.tol_res)) { status = 5; it++; break; }
         if (std::getenv("SMPC_ORACLE_TRACE"))
             std::fprintf(stderr, "it %3d a_aff %.3e sigma %.3e alpha %.3e mu %.3e rho*R0 %.3e  blocked by stage %d row %d (tl %.2e ll %.2e tu %.2e lu %.2e)\n",
                          it, a_aff, sigma, alpha, mu, rho * R0, blk_k, blk_r, S[blk_k].tl[blk_r], S[blk_k].ll[blk_r], S[blk_k].tu[blk_r], S[blk_k].lu[blk_r]);

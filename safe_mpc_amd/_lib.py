@@ -39,7 +39,7 @@ class PolicyParams(C.Structure):
 class PolicyState(C.Structure):
     """smpc_policy_state"""
     _fields_ = [(k, _vp) for k in ('x_guess', 'u_guess', 'x_temp', 'u_temp', 'p', 'x_viable', 'fails', 'current_step', 'r',
-                                   'status', 'qp_iter')]
+                                   'status', 'qp_iter', 'traj')] + [('traj_len', C.c_int64)]
 
 
 class LoopState(C.Structure):

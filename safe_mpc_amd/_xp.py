@@ -82,6 +82,10 @@ class NumpyOps:
     def clip_max(self, a, hi):
         return np.minimum(a, hi)
 
+    def swap_last(self, a):
+        """[c, B, n] -> [B, n, c]"""
+        return np.moveaxis(a, 0, -1)
+
     def host(self, a):
         return np.asarray(a)
 
@@ -155,6 +159,9 @@ class TorchOps:
 
     def clip_max(self, a, hi):
         return self.t.clamp(a, max=hi)
+
+    def swap_last(self, a):
+        return a.permute(1, 2, 0)
 
     def host(self, a):
         return a.detach().cpu().numpy()

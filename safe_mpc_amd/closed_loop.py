@@ -221,11 +221,19 @@ class _Group(InPlaceState):
     raise abort?``).  On the device every state array keeps its address (InPlaceState), so after a few eager steps each half
     is captured once as a hipGraph and replayed: one graph launch instead of ~50 kernel launches per half."""
 
-    def __init__(self, params, x_guess, u_guess, noise, control_noise, ctrl, backup, n_steps, first, callback, use_graphs):
+    def __init__(self, params, x_guess, u_guess, noise, control_noise, ctrl, backup, n_steps, first, callback, use_graphs,
+                 collect_times=False):
         self._params, self._ctrl, self._backup, self._n_steps, self._first, self._callback = params, ctrl, backup, n_steps, first, callback
         B = x_guess.shape[0]
         xp = ctrl.xp
         self._xp, self._B = xp, B
+        # stats.append(controller.getTime()) of scripts/mpc.py:239: one row of the seven time_fields per step of this group's
+        # controller.  Device path: the engine keeps HIP events of its last 64 solves (smpc_get_timing_history); they are read
+        # at least 32 solves late -- finished by then, so nothing waits inside the loop.
+        self._collect_times = bool(collect_times) and hasattr(ctrl.ocp_solver, 'timing_history')
+        self._time_rows, self._time_next, self._time_lost = [], 0, 0
+        if self._collect_times:
+            ctrl.ocp_solver.enable_timing(2)
         pr, nq, nx, nu = ctrl.problem, ctrl.nq, ctrl.nx, ctrl.nu
         self._Nb = backup.N
         seeds = np.arange(first, first + B)
@@ -377,7 +385,7 @@ class _Group(InPlaceState):
         self.u_abort = xp.where(okb[:, None, None], ua_new, self.u_abort)
         self.ja = self.ja * xp.cast(~okb, xp.i64)
         self.sa = self.sa | okb
-        self.viable = self.viable + xp.cast(okb, xp.u8)
+        self.viable = xp.cast(xp.clip_max(xp.cast(self.viable, xp.i64) + xp.cast(okb, xp.i64), 255), xp.u8)   # saturating, like k_loop_apply_backup
 
     def _apply_inflight(self):
         if self._inflight is None:
@@ -463,11 +471,39 @@ class _Group(InPlaceState):
         else:
             fn()
 
+    def _read_times(self, j, final=False):
+        """rows of the solves up to step j whose events have finished (device path: never the 32 most recent unless ``final``)"""
+        sv = self._ctrl.ocp_solver
+        while self._time_next <= j:
+            back = j - self._time_next
+            if back >= 64:                         # the ring has lapped it (the host ran more than 64 solves ahead of this read)
+                self._time_lost += 1
+                self._time_next += 1
+                continue
+            if not final and back < 32:
+                break
+            if back >= 56 or final:
+                sv.sync()                          # about to be lapped / end of the run: wait rather than lose the row
+            tm = sv.timing_history(back)
+            if tm is None:
+                if final:
+                    self._time_lost += 1
+                    self._time_next += 1
+                    continue
+                break
+            self._time_rows.append(time_row(tm))
+            self._time_next += 1
+
     def run(self):
         """generator: yields once per step, after the first half is enqueued (run_mpc serves the other groups meanwhile)"""
         xp = self._xp
         for j in range(self._n_steps):
             self._run_half('a', self.part_a, j)
+            if self._collect_times:
+                if xp.on_device:
+                    self._read_times(j)
+                else:                              # host path: the solve has finished when step() returns
+                    self._time_rows.append(self._ctrl.getTime())
             yield j
             self.handle_aborts(j)
             self._run_half('b', self.part_b, j)
@@ -478,6 +514,9 @@ class _Group(InPlaceState):
                 break
         if self._fused:
             self._apply_inflight()            # (events of the last step)
+        if self._collect_times and xp.on_device:
+            self._read_times(self._n_steps - 1, final=True)
+            self._ctrl.ocp_solver.enable_timing(0)
 
     def results(self):
         xp, ctrl, params, B, n_steps = self._xp, self._ctrl, self._params, self._B, self._n_steps
@@ -497,12 +536,26 @@ class _Group(InPlaceState):
         if not self._quirks:
             conv &= xp.host(self.alive)        # (the reference tests x_sim[-1] even of an instance it has just recorded as failed)
         return dict(x=x_sim, u=u_sim, r_receding=np.transpose(xp.host(self.r_log), (1, 0))[:, :, None], conv=conv,
+                    time_rows=np.array(self._time_rows, float).reshape(-1, len(TIME_FIELDS)), time_lost=self._time_lost,
                     collided=xp.host(self.collided), viable=xp.host(self.viable).astype(np.int64),
                     abort_events=[(e[0], e[1], e[2] if isinstance(e[2], np.ndarray) else xp.host(e[2])) for e in self._abort_events])
 
 
+TIME_FIELDS = ('time_lin', 'time_sim', 'time_qp', 'time_qp_solver_call', 'time_glob', 'time_reg', 'time_tot')   # controller.py:123-124
+
+
+def time_row(t):
+    """the engine's per-kernel times of one solve (seconds) as the reference's seven acados fields (controller.py:192-193):
+    time_lin = linearisation + network pass (acados evaluates the l4casadi row inside its linearisation), time_qp = stage-QP
+    set-up + interior point, time_qp_solver_call = the interior point alone; nothing of the kind of time_sim / time_glob /
+    time_reg runs here (closed-form dynamics, FIXED_STEP, LM folded into the set-up)"""
+    qp_setup, qp_ipm = t.get('time_qp_setup', 0.0), t.get('time_qp_ipm', 0.0)
+    qp = t['time_qp'] if 'time_qp' in t else qp_setup + qp_ipm
+    return [t.get('time_lin', 0.0) + t.get('time_nn', 0.0), 0.0, qp, qp_ipm, 0.0, 0.0, t.get('time_tot', 0.0)]
+
+
 def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, make_controller=None, make_backup=None,
-            n_steps=None, callback=False, on_device=False, device=0, timing=None, groups=None, graphs=True):
+            n_steps=None, callback=False, on_device=False, device=0, timing=None, groups=None, graphs=True, collect_times=False):
     """scripts/mpc.py:102-317 for all instances at once.  Returns the result dict the reference pickles (mpc.py:307-315).
 
     ``on_device=True``: the whole loop state -- the policy automaton of the controller, the safe-abort automaton of the driver
@@ -513,7 +566,11 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
     independent sub-batches (default 2 on the device), each with its own engine handle and HIP stream, advanced in turn:
     while the host waits for one group's flag the others' kernels keep the GPU busy, and the long tail of one group's QP
     launch overlaps the bulk of another's.  With ``graphs`` each half of a step (before / after that flag) is captured as a
-    hipGraph after a few eager steps and replayed.  ``timing``: optional dict that receives wall-clock ms per step."""
+    hipGraph after a few eager steps and replayed.  ``timing``: optional dict that receives wall-clock ms per step.
+    ``collect_times``: append the controller's solver times at every step like ``stats.append(controller.getTime())`` of
+    scripts/mpc.py:239; the result then carries ``'time_stats'`` (one row of ``TIME_FIELDS`` per step and group, seconds) and
+    ``'time_q99'`` (the 99 % quantiles mpc.py:300-303 prints).  A captured graph cannot record into the engine's event ring,
+    so this runs the steps as eager launches."""
     import time
     B = x_guess.shape[0]
     n_steps = int(n_steps if n_steps is not None else params.n_steps)
@@ -523,6 +580,8 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
     else:
         make_controller = make_controller or (lambda name, batch: get_controller(name, params, batch))
         make_backup = make_backup or (lambda batch: SafeBackupController(params, batch))
+    if collect_times:
+        graphs = False
     if groups is None:
         groups = max(1, min(2, B // 512)) if on_device else 1      # measured at B = 4096 (MI355X, r2): 1: 5.1, 2: 4.55, 3: 5.8 ms/step
     from .sharding import shard_range
@@ -536,10 +595,12 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
             sv = ctrl.ocp_solver
             streams.append(torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=torch.device('cuda', sv.device)))
             with torch.cuda.stream(streams[-1]):
-                grp = _Group(params, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo, callback, graphs)
+                grp = _Group(params, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo, callback, graphs,
+                             collect_times)
         else:
             streams.append(None)
-            grp = _Group(params, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo, callback, False)
+            grp = _Group(params, x_guess[lo:hi], u_guess[lo:hi], noise, control_noise, ctrl, backup, n_steps, lo, callback, False,
+                         collect_times)
         grps.append(grp)
         gens.append(grp.run())
 
@@ -610,7 +671,12 @@ def run_mpc(params, cont_name, x_guess, u_guess, noise=0.0, control_noise=0.0, m
         x_viable = np.zeros((0, x_sim.shape[2]))
     # 'r': the reference allocates r_index as NaN and never writes it (mpc.py:116, 281) -- kept NaN for format parity; the
     # receding index actually used at every step is returned next to it as 'r_receding' (-1 where the policy has none)
-    return {'x': x_sim, 'u': np.concatenate([o['u'] for o in outs], axis=0),
+    extra = {}
+    if collect_times:
+        ts = np.concatenate([o['time_rows'] for o in outs], axis=0)
+        extra = {'time_stats': ts, 'time_fields': list(TIME_FIELDS), 'time_lost': int(sum(o['time_lost'] for o in outs)),
+                 'time_q99': np.quantile(ts, 0.99, axis=0) if len(ts) else np.zeros(len(TIME_FIELDS))}
+    return {**extra, 'x': x_sim, 'u': np.concatenate([o['u'] for o in outs], axis=0),
             'r': np.full((B, n_steps, 1), np.nan), 'r_receding': np.concatenate([o['r_receding'] for o in outs], axis=0),
             'conv_idx': conv_idx, 'collisions_idx': coll_idx, 'unconv_idx': unconv_idx, 'viable_idx': viable_idx,
             'x_viable': x_viable}

@@ -64,6 +64,7 @@ class AbstractController(InPlaceState):
         self.p[:, :, :3] = xp.asarray(self.problem.ee_ref, xp.f64)
         self.p[:, :, 3] = self.params.alpha
         self.p[:, :, 4] = 1.0
+        self.traj = getattr(self, 'traj', None)                    # reference trajectory (setTrajectory); None = constant ee_ref
         self.last_status = xp.full((B,), 4, xp.i32)                # controller.py:125
         self.qp_iter = xp.zeros((B,), xp.i32)
         self.x_viable = xp.zeros((B, self.nx))
@@ -80,6 +81,31 @@ class AbstractController(InPlaceState):
         self.problem.ee_ref = np.asarray(ee_ref, float)
         self.p[:, :, :3] = self.xp.asarray(self.problem.ee_ref, self.xp.f64)
 
+    def setTrajectory(self, traj):
+        """``cost.traj`` of the reference (cost_definition.py:30-31, 89): ``[3, n_steps + 1 + N]`` reference points, of which
+        ``solve`` hands node i the column ``current_step + i`` (controller.py:153-156).  ``None`` (the default) = the constant
+        ``ee_ref`` of the ReachTarget / Zero costs, for which the indexing changes nothing."""
+        if traj is None:
+            self.traj = None
+            self.p[:, :, :3] = self.xp.asarray(self.problem.ee_ref, self.xp.f64)
+            return
+        traj = np.ascontiguousarray(traj, float)
+        if traj.ndim != 2 or traj.shape[0] != 3 or traj.shape[1] < 1:
+            raise ValueError('traj must be [3, n_columns]')
+        self.traj = self.xp.asarray(traj, self.xp.f64)
+
+    def _apply_traj(self, rows=None):
+        """p[b, i, 0:3] = traj[:, current_step[b] + i] (controller.py:153-156)"""
+        if self.traj is None:
+            return
+        xp = self.xp
+        col = xp.clip_max(self.current_step[:, None] + xp.arange(self.N + 1)[None, :], self.traj.shape[1] - 1)     # [B, N+1]
+        ref = xp.swap_last(self.traj[:, col])                  # [3, B, N+1] -> [B, N+1, 3]
+        if rows is None:
+            self.p[:, :, :3] = ref
+        else:
+            self.p[:, :, :3] = xp.where(rows[:, None, None], ref, self.p[:, :, :3])
+
     def setGuess(self, x_guess, u_guess):
         self.x_guess = self.xp.asarray(x_guess, self.xp.f64)
         self.u_guess = self.xp.asarray(u_guess, self.xp.f64)
@@ -91,11 +117,13 @@ class AbstractController(InPlaceState):
         return self.xp.copy(self.x_viable)
 
     def getTime(self):
+        """controller.py:192-193: the seven acados timers of the last solve, in seconds (zeros when timing is off)"""
+        from .closed_loop import time_row
         try:
-            t = self.ocp_solver.timing()
+            t = self.ocp_solver.timing_history(0) if hasattr(self.ocp_solver, 'timing_history') else self.ocp_solver.timing()
         except Exception:
-            t = {}
-        return np.array([t.get(f, 0.0) for f in self.time_fields])
+            t = None
+        return np.array(time_row(t)) if t else np.zeros(len(self.time_fields))
 
     def resetHorizon(self, N):
         """controller.py:205-214: new horizon without re-creating the solver."""
@@ -109,6 +137,7 @@ class AbstractController(InPlaceState):
     def solve(self, x0):
         """controller.py:136-167 for all instances: returns status[B]; x_temp / u_temp hold the iterate regardless."""
         self.p[:, :, 3] = self.params.alpha
+        self._apply_traj()
         if not self.xp.on_device:
             x0 = np.asarray(x0, float)
         if self.xp.on_device:     # the engine writes straight into the controller's persistent buffers

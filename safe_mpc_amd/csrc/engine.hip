@@ -72,8 +72,10 @@ struct smpc_handle {
     // last EV_RING solves afterwards (smpc_get_timing_history), without a synchronisation inside the loop
     static constexpr int EV_RING = 64;
     hipEvent_t ev_sets[EV_RING][5] = {};
+    bool ev_complete[EV_RING] = {};   // all five events of the slot were recorded by ONE solve (cleared when the slot is reused)
     hipEvent_t* ev_t = ev_sets[0];
     int ev_cur = 0;
+    bool timing_now = false;    // this solve records its events (timing on and the stream is not being captured into a graph)
     long timed_count = 0;       // solves timed since timing was enabled
     // sub-batch workers of smpc_rollout_batch: full handles on their own streams that borrow this handle's network weights
     std::vector<smpc_handle*> kids;
@@ -289,14 +291,16 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
 }
 
 template <int NQ>
-int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, const double* d_p, double* d_ev) {
+int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, const double* d_p, double* d_ev, bool timed = false) {
+    // (timed: called from launch_solve, which owns the current slot of the event ring; smpc_eval_nodes on its own records nothing --
+    //  it would re-record two events of the last solve's slot and leave that slot's durations meaningless)
     const int N = h->N;
     hipStream_t s = h->stream;
     const long n1 = (long)B * (N + 1);
     hipLaunchKernelGGL((k_node_linearise<NQ>), dim3((unsigned)((n1 + 63) / 64)), dim3(64), 0, s, h->d_desc, B, N, d_xg, d_ug,
                        d_p, d_ev);
     HIPCHK(h, hipGetLastError());
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
+    if (timed) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
     if (h->desc.nn_mode != SMPC_NN_NONE) {
         if (h->nlayers == 0) return fail(h, SMPC_ESTATE, "nn_mode != NONE but smpc_set_mlp was not called");
         // row on every node: only the nodes whose per-node switch is on are evaluated (compacted list, mode 3)
@@ -316,7 +320,7 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
                                mode == 3 ? h->d_nn_cnt : (const int32_t*)nullptr);
         HIPCHK(h, hipGetLastError());
     }
-    if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[2], s));
+    if (timed) HIPCHK(h, hipEventRecord(h->ev_t[2], s));
     return SMPC_OK;
 }
 
@@ -331,13 +335,22 @@ template <int NQ>
 int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
                  double* xo, double* uo, int32_t* st, int32_t* it) {
     int rc;
+    h->timing_now = false;
     if (h->timing) {
+        // a solve that is being captured into a hipGraph records nothing: every replay would re-record the one slot it captured
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        h->timing_now = cs == hipStreamCaptureStatusNone;
+    }
+    const bool timed = h->timing_now;
+    if (timed) {
         h->ev_cur = (h->ev_cur + 1) % smpc_handle::EV_RING;
         h->ev_t = h->ev_sets[h->ev_cur];
+        h->ev_complete[h->ev_cur] = false;      // (an error return below leaves the slot invalid, not stale)
         h->timed_count++;
         HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
     }
-    if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev))) return rc;
+    if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev, timed))) return rc;
     // fast path: the row count of the reference's default geometry (6 capsule pairs, config.yaml:205-216) is a
     // compile-time constant of the kernel; any other geometry takes the runtime-row-count instantiation
     const bool per_inst = h->inst_B == B;
@@ -351,7 +364,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     }
     const int tiles = (int)ev_tiles((size_t)B * (h->N + 1));
     unsigned long long* wstat = nullptr;
-    if (h->timing == 1) {      // (timing mode 2: events only, no in-kernel load-balance probe)
+    if (timed && h->timing == 1) {      // (timing mode 2: events only, no in-kernel load-balance probe)
         if (!h->d_wstat) HIPCHK(h, hipMalloc((void**)&h->d_wstat, 4 * sizeof(unsigned long long)));
         const unsigned long long init[4] = {0ull, ~0ull, 0ull, 0ull};
         HIPCHK(h, hipMemcpyAsync(h->d_wstat, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
@@ -363,7 +376,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     do {                                                                                                                           \
         hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
                            bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                                  \
-        if (h->timing) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                           \
+        if (timed) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                               \
         hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
                            ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active);                                  \
     } while (0)
@@ -375,7 +388,11 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
 #undef SMPC_QP_LAUNCH
     h->order_B = B;
     HIPCHK(h, hipGetLastError());
-    if (h->timing) { HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream)); h->timed = 1; }
+    if (timed) {
+        HIPCHK(h, hipEventRecord(h->ev_t[3], h->stream));
+        h->ev_complete[h->ev_cur] = true;
+        h->timed = 1;
+    }
     return SMPC_OK;
 }
 
@@ -1059,7 +1076,9 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
     int32_t* d_acc = d_safe + (size_t)B * (N + 1);
     uint8_t* d_act = (uint8_t*)(d_acc + B);
     if (kind != SMPC_POLICY_NAIVE && (rc = upload_check_bounds(h, par->x_min, par->x_max, par->row_lb_chk, par->row_ub_chk))) return rc;
-    // guessCorrection (not RealReceding, controller.py:524-565); the launch also resets *any_abort
+    // guessCorrection (not RealReceding, controller.py:524-565); the launch also resets *any_abort.  Every kind launches exactly
+    // one of the two kernels that do so -- k_guess_correction here, k_policy_pre (RealReceding) below -- and both grids are
+    // non-empty (B > 0, nq > 0), so thread 0 of block 0 always exists.
     if (kind != SMPC_POLICY_REAL_RECEDING)
         hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 63) / 64), dim3(64), 0, s, B, N, nq, h->desc.dt, st->x_guess,
                            st->u_guess, stepping, any_abort);
@@ -1080,6 +1099,11 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
         hipLaunchKernelGGL(k_policy_pre, dim3((unsigned)(((size_t)B * (N + 1) + 63) / 64)), dim3(64), 0, s, B, N, nx, kind,
                            stepping, st->r, st->p, st->x_guess, par->stage_lo, par->stage_hi, par->tube, h->d_lo_b, h->d_hi_b,
                            kind == SMPC_POLICY_REAL_RECEDING ? any_abort : (int32_t*)nullptr);
+    }
+    if (st->traj) {      // controller.py:153-156: the nodes' reference points follow the step counter
+        if (st->traj_len < 1) return fail(h, SMPC_EINVAL, "traj_len must be >= 1");
+        hipLaunchKernelGGL(k_policy_traj, dim3((unsigned)(((size_t)B * (N + 1) + 63) / 64)), dim3(64), 0, s, B, N, stepping,
+                           st->current_step, st->traj, (long)st->traj_len, st->p);
     }
     HIPCHK(h, hipGetLastError());
     h->d_active = stepping;
@@ -1195,13 +1219,14 @@ int smpc_enable_timing(smpc_handle* h, int on) {
     h->timing = on == 2 ? 2 : (on ? 1 : 0);
     h->timed = 0;
     h->timed_count = 0;
+    for (bool& c : h->ev_complete) c = false;
     return SMPC_OK;
 }
 
 int smpc_get_timing(smpc_handle* h, float* ms4) {
     if (!h || !ms4) return SMPC_EINVAL;
     if (!h->timing) return fail(h, SMPC_ESTATE, "timing not enabled");
-    if (!h->timed) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
+    if (!h->timed || !h->ev_complete[h->ev_cur]) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
     (void)hipSetDevice(h->device);
     HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
     HIPCHK(h, hipEventElapsedTime(&ms4[0], h->ev_t[0], h->ev_t[1]));
@@ -1214,7 +1239,7 @@ int smpc_get_timing(smpc_handle* h, float* ms4) {
 int smpc_get_qp_timing(smpc_handle* h, float* ms2) {
     if (!h || !ms2) return SMPC_EINVAL;
     if (!h->timing) return fail(h, SMPC_ESTATE, "timing not enabled");
-    if (!h->timed) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
+    if (!h->timed || !h->ev_complete[h->ev_cur]) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
     (void)hipSetDevice(h->device);
     HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
     HIPCHK(h, hipEventElapsedTime(&ms2[0], h->ev_t[2], h->ev_t[4]));
@@ -1227,7 +1252,9 @@ int smpc_get_timing_history(smpc_handle* h, int back, float* ms6) {
     for (int i = 0; i < 6; i++) ms6[i] = 0.0f;
     if (!h->timing || back >= smpc_handle::EV_RING || (long)back >= h->timed_count) return SMPC_OK;
     (void)hipSetDevice(h->device);
-    hipEvent_t* ev = h->ev_sets[(h->ev_cur - back + 2 * smpc_handle::EV_RING) % smpc_handle::EV_RING];
+    const int slot = (h->ev_cur - back + 2 * smpc_handle::EV_RING) % smpc_handle::EV_RING;
+    if (!h->ev_complete[slot]) return SMPC_OK;     // the solve that owns the slot returned early: valid stays 0
+    hipEvent_t* ev = h->ev_sets[slot];
     if (hipEventQuery(ev[3]) != hipSuccess) { (void)hipGetLastError(); return SMPC_OK; }   // not finished yet: valid stays 0
     HIPCHK(h, hipEventElapsedTime(&ms6[0], ev[0], ev[1]));
     HIPCHK(h, hipEventElapsedTime(&ms6[1], ev[1], ev[2]));

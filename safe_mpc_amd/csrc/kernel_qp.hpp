@@ -1472,10 +1472,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         pending = true;
         rho_lin *= (1.0 - alpha);
         // sum(lambda t) is a quadratic in the step length: the new complementarity is known before the step is applied
+        const double mu_before = mu;
         mu = (mu * (double)m_comp + alpha * S1c + alpha * alpha * S2c) * inv_m;
         if (!(mu == mu)) { st_code = 4; pending = false; break; }
-        stall = alpha < 0.5 ? stall + 1 : 0;
-        if (stall_max > 0 && stall >= stall_max) { st_code = 5; it++; break; }    // (the step just computed is still applied)
+        // a stalled iteration: a short step that did not halve the complementarity either (a degenerate but feasible QP
+        // crawls with short steps while mu still falls); an iterate that meets the exit test is never reported as stalled
+        stall = (alpha < 0.5 && !(mu < 0.5 * mu_before)) ? stall + 1 : 0;
+        if (stall_max > 0 && stall >= stall_max && !(mu <= tol && rho_lin * R0 <= tol_r)) { st_code = 5; it++; break; }    // (the step just computed is still applied)
     }
     if (it == max_iter && st_code == 2 && mu <= tol && rho_lin * R0 <= tol_r) st_code = 0;
 

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64) void k_plant_step(const smpc_problem_desc* __re
 
 // sums over a batch, accumulated across calls (a closed loop's counters stay on the device):
 // acc[0] += sum of IPM iterations, acc[1] += solves with status != 0, acc[2] += solves
-__global__ __launch_bounds__(256) void k_accumulate_stats(int B, const int32_t* __restrict__ status, const int32_t* __restrict__ qp_iter,
+// (one wavefront per block, like every short kernel of the loop: the reduction below is a wave-wide xor-shuffle)
+__global__ __launch_bounds__(64) void k_accumulate_stats(int B, const int32_t* __restrict__ status, const int32_t* __restrict__ qp_iter,
                                                           unsigned long long* __restrict__ acc) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long it = 0, bad = 0, n = 0;

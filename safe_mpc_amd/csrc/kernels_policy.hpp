@@ -36,6 +36,21 @@ __global__ void k_policy_pre(int B, int N, int nx, int kind, const uint8_t* __re
     }
 }
 
+// solve() feeds every node its column of the reference trajectory, p[i][0:3] = cost.traj[:, current_step + i]
+// (controller.py:153-156; cost_definition.py:30-31, 89: traj has n_steps + 1 + N columns).  One thread per (instance, node);
+// launched only when the caller gave a trajectory.
+__global__ void k_policy_traj(int B, int N, const uint8_t* __restrict__ stepping, const int64_t* __restrict__ current_step,
+                              const double* __restrict__ traj, long traj_len, double* __restrict__ p) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)B * (N + 1)) return;
+    const long b = t / (N + 1);
+    const int k = (int)(t - b * (N + 1));
+    if (stepping && !stepping[b]) return;
+    long c = (long)current_step[b] + k;
+    c = c < 0 ? 0 : (c < traj_len ? c : traj_len - 1);
+    for (int i = 0; i < 3; i++) p[t * SMPC_NP + i] = traj[(size_t)i * traj_len + c];
+}
+
 // The receding policies move r to the last safe node of the NEW trajectory, looking at nodes r + 2 .. N only
 // (controller.py:491-494) -- in steady state one or two nodes per instance.  This builds the list of those (instance, node) pairs
 // so that the network is evaluated there and nowhere else.  r is taken after this step's decrement / abort reset, exactly as

@@ -14,7 +14,7 @@ import numpy as np
 
 from .urdf import SerialChain
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_NQ, MAX_NX, MAX_POINTS, MAX_ROWS, MAX_LAYERS, MAX_N, NP = 7, 14, 12, 12, 6, 63, 5
 INF = 1.0e5
 

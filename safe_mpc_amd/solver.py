@@ -86,8 +86,8 @@ class BatchedOcpSolver:
         bp = (C.c_void_p * n)(*[b.ctypes.data for b in bs])
         self._chk(self.L.smpc_set_mlp(self.h, n, dims.ctypes.data_as(C.POINTER(C.c_int32)), Wp, bp, 0))
         act = getattr(net, 'act', 'gelu')
-        codes = {'gelu': 0, 'relu': 1, 'elu': 2, 'tanh': 3, 'silu': 4}                 # SMPC_ACT_* (parser.py:95-102)
-        self._chk(self.L.smpc_set_mlp_activation(self.h, codes[act]))
+        from .safe_set import SafeSetNet
+        self._chk(self.L.smpc_set_mlp_activation(self.h, SafeSetNet.ACT_CODES[act]))      # SMPC_ACT_* (parser.py:95-102)
         self.net = net
 
     def set_horizon(self, N):
@@ -362,7 +362,8 @@ class BatchedOcpSolver:
                                  getattr(ctrl, '_stage_lo', None), getattr(ctrl, '_stage_hi', None))
         st = _lib.PolicyState(ptr(ctrl.x_guess), ptr(ctrl.u_guess), ptr(ctrl.x_temp), ptr(ctrl.u_temp), ptr(ctrl.p), ptr(ctrl.x_viable),
                               ptr(ctrl.fails), ptr(ctrl.current_step), ptr(getattr(ctrl, 'r', None)), ptr(ctrl.last_status),
-                              ptr(ctrl.qp_iter))
+                              ptr(ctrl.qp_iter), ptr(getattr(ctrl, 'traj', None)),
+                              int(ctrl.traj.shape[1]) if getattr(ctrl, 'traj', None) is not None else 0)
         u_out = ctrl._u_out if u_out is None else u_out
         with self._ordered(1):
             self._chk(self.L.smpc_policy_step(self.h, ctrl.B, C.byref(pp), C.byref(st), x.data_ptr(), ptr(stepping), ptr(u_other),

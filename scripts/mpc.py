@@ -29,8 +29,13 @@ def main(argv=None):
     tm = {}
     # all loop state in HBM (policy automaton, abort handling, logs); SMPC_HOST_STATE=1 keeps it in numpy arrays instead
     res = cl.run_mpc(params, cont_name, x_guess, u_guess, noise=args['noise'], control_noise=args['control_noise'],
-                     callback=True, on_device=os.environ.get('SMPC_HOST_STATE', '0') != '1', timing=tm)
+                     callback=True, on_device=os.environ.get('SMPC_HOST_STATE', '0') != '1', timing=tm,
+                     collect_times=os.environ.get('SMPC_NO_TIME_STATS', '0') != '1')
     print(f"{tm['ms_per_step']:.3f} ms per closed-loop step of {x_guess.shape[0]} instances")
+    if 'time_stats' in res:      # the block of the reference's mpc.py:300-303 (here one solve = all instances of a group)
+        print('99% quantile of the computation time:')
+        for field, t in zip(res['time_fields'], res['time_q99']):
+            print(f"{field:<20} -> {t}")
     n = x_guess.shape[0]
     print(f"Completed task: {len(res['conv_idx'])}\nCollisions: {len(res['collisions_idx'])}"
           f"\nViable states: {len(res['viable_idx'])}\nNot converged: {n - len(res['conv_idx']) - len(res['collisions_idx'])}")

@@ -29,7 +29,11 @@ class OracleSolver:
         pass
 
     def solve(self, x0, xg, ug, p, out=None):
+        import time
+        t0 = time.perf_counter()
         x, u, st, it = self.o.solve_batch(x0, xg, ug, p)
+        dt = time.perf_counter() - t0
+        self._last_times = {'time_lin': 0.0, 'time_nn': 0.0, 'time_qp_setup': 0.0, 'time_qp_ipm': dt, 'time_tot': dt}
         if self.scripted_status:
             st = np.asarray(self.scripted_status.pop(0), np.int32)
         return x, u, st, it
@@ -58,6 +62,9 @@ class OracleSolver:
 
     def timing(self):
         return {}
+
+    def timing_history(self, back=0):
+        return getattr(self, '_last_times', None) if back == 0 else None
 
     def sync(self):
         pass

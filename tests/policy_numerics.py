@@ -26,10 +26,10 @@ class SolverNumerics:
         x, u = np.asarray(x, float), np.asarray(u, float)
         return np.concatenate([x[:nq] + dt * x[nq:] + 0.5 * dt * dt * u, x[nq:] + dt * u])
 
-    def solve(self, x0, x_guess, u_guess, flags, lo, hi):
+    def solve(self, x0, x_guess, u_guess, flags, lo, hi, ref=None):
         N = self.N
         p = np.zeros((1, N + 1, 5))
-        p[0, :, :3] = self.pr.ee_ref
+        p[0, :, :3] = self.pr.ee_ref if ref is None else np.asarray(ref, float)
         p[0, :, 3] = self.par.alpha
         p[0, :, 4] = np.asarray(flags, float)
         if lo is not None:

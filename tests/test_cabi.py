@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     L.smpc_abi_version.restype = C.c_int
-    assert L.smpc_abi_version() == 4
+    assert L.smpc_abi_version() == 5
 
 
 def test_struct_mirrors_match_header_sizes():

@@ -111,3 +111,69 @@ def test_generate_guess_merit_backtracking_on_oracle_double():
         C.AbstractController.__init__(ctrl, par2, batch, 'nls', 8, solver=OracleSolver(prob, net), net=net)
         return ctrl
     _merit_sqp_checks(mk2, par2, 'zerovel', 4)
+
+
+def test_real_receding_closed_loop_same_outcomes_with_and_without_stall_exit():
+    """the stall exit (qp_stall_iters = 24, RealReceding's default) must only shorten solves that fail anyway.  The
+    same closed loop with the exit off and on: identical statuses at every step (so identical accept / reject / abort
+    decisions, hence trajectories), the failed solves of the 'on' run are the failed solves of the 'off' run, and none of
+    the 'on' run's failures is an iterate that met the exit test (those report success)."""
+    from conftest import sample_instances
+    N, B, steps = 30, 48, 16
+    logs = {}
+    for stall in (0, 24):
+        par, prob, net = make_problem('real_receding', N=N, qp_stall_iters=stall)
+        par.back_hor = 30
+        assert prob.desc.qp_stall_iters == stall
+        log = []
+
+        class Logging(OracleSolver):
+            def solve(self, x0, xg, ug, p, out=None):
+                r = super().solve(x0, xg, ug, p, out)
+                log.append((np.asarray(r[2]).copy(), np.asarray(r[3]).copy(), np.asarray(r[1][:, 0]).copy()))
+                return r
+
+        def mk(name, batch, par=par):
+            cls = C.CONTROLLERS[name]
+            ctrl = cls.__new__(cls)
+            pr = C.OcpProblem(par, cls.cont_name, 'ext', N=N)
+            nt = C.SafeSetNet.from_params(par, pr.x_min, pr.x_max)
+            pr.set_normalisation(nt.mean, nt.std)
+            C.AbstractController.__init__(ctrl, par, batch, 'ext', N, solver=Logging(pr, nt), net=nt)
+            return ctrl
+        _, mkb = _factories(par, N)
+        x0 = sample_instances(prob, B, seed=0)
+        res = cl.run_mpc(par, 'real_receding', np.repeat(x0[:, None, :], N + 1, axis=1), np.zeros((B, N, 6)), make_controller=mk,
+                         make_backup=mkb, n_steps=steps)
+        logs[stall] = (log, res)
+    (l0, r0), (l1, r1) = logs[0], logs[24]
+    assert len(l0) == len(l1)
+    n_fail = 0
+    for (s0, i0, u0), (s1, i1, u1) in zip(l0, l1):
+        assert np.array_equal(s0, s1)                     # same verdict for every solve
+        ok = s0 == 0
+        assert np.array_equal(i0[ok], i1[ok]) and np.array_equal(u0[ok], u1[ok])      # successful solves: bit-identical
+        assert np.all(i1[~ok] <= i0[~ok])                 # failing ones only get shorter
+        n_fail += int((~ok).sum())
+    assert n_fail > 0, 'the fixture is meant to contain infeasible tubes'
+    for key in ('conv_idx', 'collisions_idx', 'viable_idx', 'unconv_idx'):
+        assert r0[key] == r1[key]
+    assert np.array_equal(np.nan_to_num(r0['x']), np.nan_to_num(r1['x']))
+
+
+def test_run_mpc_collects_solver_times_like_the_reference():
+    """scripts/mpc.py:239,300-303: one row of the seven acados timers per step, and their 99 % quantiles"""
+    par, prob, net = make_problem('st', N=8)
+    par.back_hor = 10
+    mk, mkb = _factories(par, 8)
+    from conftest import sample_instances
+    x0 = sample_instances(prob, 4, seed=1)
+    res = cl.run_mpc(par, 'st', np.repeat(x0[:, None, :], 9, axis=1), np.zeros((4, 8, 6)), make_controller=mk, make_backup=mkb,
+                     n_steps=6, collect_times=True)
+    ts = res['time_stats']
+    assert res['time_fields'] == ['time_lin', 'time_sim', 'time_qp', 'time_qp_solver_call', 'time_glob', 'time_reg', 'time_tot']
+    assert ts.shape == (6, 7) and res['time_lost'] == 0
+    assert np.all(ts[:, 6] > 0) and np.all(ts[:, 6] >= ts[:, 2]) and np.all(ts[:, 2] >= ts[:, 3])
+    assert np.allclose(res['time_q99'], np.quantile(ts, 0.99, axis=0))
+    ref = cl.run_mpc(par, 'st', np.repeat(x0[:, None, :], 9, axis=1), np.zeros((4, 8, 6)), make_controller=mk, make_backup=mkb, n_steps=6)
+    assert 'time_stats' not in ref and np.array_equal(ref['x'], res['x'])      # collecting times changes nothing else

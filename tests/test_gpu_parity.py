@@ -627,6 +627,63 @@ def test_policy_step_kernels_equal_scalar_oracle(name):
         assert n_abort > 0
 
 
+@pytest.mark.parametrize('name', ['st', 'htwa', 'receding'])
+def test_policy_step_reference_trajectory_advances_with_the_step(name):
+    """smpc_policy_state.traj -- p[b][i][0:3] = traj[:, current_step[b] + i] before every solve
+    (controller.py:153-156, cost_definition.py:30-31) -- on the device against the scalar oracle carrying the same moving
+    trajectory; an instance that aborts does not advance its step and sees the same columns again."""
+    import torch
+    from oracle import policy_oracle as po
+    from policy_numerics import SolverNumerics
+    from safe_mpc_amd import controller as C
+    from safe_mpc_amd.parser import Parameters
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N = 6, 6, [12, 256, 1], 8
+    N, B, steps = 8, 10, 20
+    dev = C.get_controller(name, par, B, device_state=True)
+    x0 = sample_instances(dev.problem, B, seed=3, vel_scale=0.3)
+    xg, ug = np.repeat(x0[:, None, :], N + 1, axis=1), np.zeros((B, N, 6))
+    dev.setGuess(xg, ug)
+    t_ = np.arange(steps + 1 + N) * 0.15
+    traj = np.asarray(dev.problem.ee_ref, float)[:, None] + 0.05 * np.vstack([np.cos(t_) - 1.0, np.sin(t_), 0.5 * np.sin(2 * t_)])
+    dev.setTrajectory(traj)
+    host_solver = BatchedOcpSolver(dev.problem, dev.net)
+    insts, nums = [], []
+    for b in range(B):
+        inst = po.PolicyInstance(name, N, dev.nx, dev.nu, abort_flag=bool(par.abort_flag))
+        inst.set_guess(xg[b], ug[b])
+        inst.reset()
+        inst.traj = traj
+        insts.append(inst)
+        nums.append(SolverNumerics(host_solver, dev.problem, par))
+    x = x0.copy()
+    n_abort = 0
+    for t in range(steps):
+        cs = [inst.current_step for inst in insts]
+        ud, ad = dev.step_on_device(torch.tensor(x, device='cuda'))
+        dev.ocp_solver.sync()
+        ud, ad, pd = ud.cpu().numpy(), ad.cpu().numpy(), dev.p.cpu().numpy()
+        for b in range(B):
+            assert np.array_equal(pd[b, :, :3], traj[:, cs[b]:cs[b] + N + 1].T), (t, b)      # the columns of THIS solve
+            uo, ao = po.step(insts[b], nums[b], x[b])
+            assert bool(ad[b]) == ao, (t, b)
+            assert np.abs(ud[b] - uo).max() < 1e-4 * (1 + np.abs(uo).max()), (t, b)
+            assert int(dev.current_step[b]) == insts[b].current_step, (t, b)
+            n_abort += int(ao)
+        x = x + par.dt * np.hstack([x[:, 6:], ud])
+        if t >= 2:
+            x[:max(B // 4, 1), 6] = 1.5 * dev.problem.x_max[6]       # outside the velocity limits: reject / abort branches
+    if dev.can_abort:
+        assert n_abort > 0
+    # traj = NULL leaves p[:, :, 0:3] alone (the constant ee_ref of the in-scope costs)
+    dev.setTrajectory(None)
+    before = dev.p.clone()
+    dev.step_on_device(torch.tensor(x, device='cuda'))
+    dev.ocp_solver.sync()
+    assert torch.equal(dev.p[:, :, :3], before[:, :, :3])
+
+
 @pytest.mark.parametrize('name', ['htwa', 'receding'])
 def test_device_policy_loop_equals_scalar_oracle_loop(name):
     """... and the whole closed loop with all state in HBM (run_mpc(on_device=True): smpc_loop_pre / smpc_policy_step /

@@ -235,3 +235,78 @@ def test_numpy_mirror_step_equals_scalar_oracle_step(kind):
         x = x + par.dt * np.hstack([x[:, 6:], um]) + rng.normal(scale=1e-3, size=x.shape)
     if mirror.can_abort:
         assert seen_abort
+
+
+def _moving_traj(ee_ref, n_cols):
+    """a reference that moves with the step (controller.py:153-156 indexes cost.traj by current_step + i): a small circle
+    around the configured ee_ref"""
+    t = np.arange(n_cols) * 0.15
+    return np.asarray(ee_ref, float)[:, None] + 0.05 * np.vstack([np.cos(t) - 1.0, np.sin(t), 0.5 * np.sin(2 * t)])
+
+
+@pytest.mark.parametrize('kind', ['st', 'htwa', 'receding'])
+def test_reference_trajectory_advances_with_the_step(kind):
+    """p[i][0:3] = cost.traj[:, current_step + i] at every solve (controller.py:153-156,
+    cost_definition.py:30-31).  The numpy mirror with setTrajectory against the scalar oracle with inst.traj, step by step, with
+    rejected solves and (htwa / receding) aborts in the script: an aborting instance returns before `current_step += 1`
+    (controller.py:384-385, 483-487) and must see the SAME columns again at its next solve."""
+    N, B = 6, 4
+    par = _params(N, 4, True)
+    rng = np.random.default_rng(3)
+    mirror = _swap_solver(make_double_controller(kind, par, B), ScriptedSolver)
+    x0 = sample_instances(mirror.problem, B, seed=2, vel_scale=0.05)
+    xg, ug = np.repeat(x0[:, None, :], N + 1, axis=1), rng.normal(scale=0.1, size=(B, N, 6))
+    steps = 3 * N
+    traj = _moving_traj(mirror.problem.ee_ref, steps + 1 + N)
+    mirror.setGuess(xg.copy(), ug.copy())
+    mirror.reset_controller()
+    mirror.setTrajectory(traj)
+    if kind == 'receding':
+        mirror.checkSafeConstraints = lambda x: _vec_safe(x)
+    matrix = [[(4 if (b == 1 and j >= 2) or (b == 2 and j % 5 == 1) else 0) for b in range(B)] for j in range(steps)]
+    mirror.ocp_solver.matrix = matrix
+    seen_p = []
+    orig = mirror.ocp_solver.solve
+    mirror.ocp_solver.solve = lambda x0_, xg_, ug_, p_, out=None: (seen_p.append(np.array(p_)), orig(x0_, xg_, ug_, p_, out))[1]
+    insts, nums = [], []
+    for b in range(B):
+        num = SolverNumerics(OracleSolver(mirror.problem, mirror.net), mirror.problem, par)
+        num.status_script = (lambda j, b=b: matrix[j][b])
+        if kind == 'receding':
+            num.safe_script = _safe_rule
+        inst = po.PolicyInstance(kind, N, mirror.nx, mirror.nu, abort_flag=True)
+        inst.set_guess(xg[b], ug[b])
+        inst.reset()
+        inst.traj = traj
+        insts.append(inst)
+        nums.append(num)
+    x = x0.copy()
+    seen_abort = False
+    for j in range(steps):
+        cs = [inst.current_step for inst in insts]
+        um, am = mirror.step(x)
+        for b in range(B):
+            # what the mirror handed the solver at this step: the columns current_step + i of traj
+            assert np.array_equal(seen_p[-1][b, :, :3], traj[:, cs[b]:cs[b] + N + 1].T), (j, b)
+            nums[b].on_step(j)
+            uo, ao = po.step(insts[b], nums[b], x[b])
+            assert bool(am[b]) == ao, (j, b)
+            assert np.abs(um[b] - uo).max() < 1e-8 * (1 + np.abs(uo).max()), (j, b)
+            assert int(mirror.current_step[b]) == insts[b].current_step, (j, b)
+            seen_abort |= ao
+        x = x + par.dt * np.hstack([x[:, 6:], um]) + rng.normal(scale=1e-3, size=x.shape)
+    if mirror.can_abort:
+        assert seen_abort
+    # the moving reference matters: the same loop with the constant ee_ref gives other controls
+    const = _swap_solver(make_double_controller(kind, par, B), ScriptedSolver)
+    const.setGuess(xg.copy(), ug.copy())
+    const.reset_controller()
+    u_c, _ = const.step(x0)
+    moving = _swap_solver(make_double_controller(kind, par, B), ScriptedSolver)
+    moving.setGuess(xg.copy(), ug.copy())
+    moving.reset_controller()
+    moving.setTrajectory(traj + 0.1)
+    u_m, _ = moving.step(x0)
+    assert np.abs(u_c - u_m).max() > 1e-3
+    moving.setTrajectory(None)                                       # back to the constant ee_ref
+    assert np.array_equal(moving.p[:, :, :3], const.p[:, :, :3])
