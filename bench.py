@@ -73,6 +73,43 @@ def algorithmic_bytes(nq, N):
     return 8 * (nx + (N + 1) * nx + N * nu + (N + 1) * 5) + 8 * ((N + 1) * nx + N * nu) + 4
 
 
+def in_loop_kernel_times(solvers, step_fn, sync_fn, n_steps):
+    """Continue a closed loop for n_steps with the engines' HIP-event rings on (smpc_enable_timing(2)) and return, per solver,
+    the mean per-launch durations in ms: [linearise, mlp, qp_setup, qp_ipm, solve_total] (None where nothing was read).  Used
+    AFTER a script's timed region, so that the timed region itself records no events."""
+    n_steps = min(n_steps, 60)
+    for sv in solvers:
+        sv.enable_timing(2)
+    sync_fn()
+    for _ in range(n_steps):
+        step_fn()
+    sync_fn()
+    out = []
+    for sv in solvers:
+        rows = []
+        for back in range(n_steps):
+            tm = sv.timing_history(back)
+            if tm is not None:
+                rows.append([tm['time_lin'], tm['time_nn'], tm['time_qp_setup'], tm['time_qp_ipm'], tm['time_tot']])
+        sv.enable_timing(0)
+        out.append(1e3 * np.mean(rows, axis=0) if rows else None)
+    return out
+
+
+def roofline_of_launches(alg_bytes, ipm_ms, traffic_bytes_per_instance_iteration=None, instance_iterations=None):
+    """`roofline` block for a set of k_qp_ipm launches: alg_bytes[i] = algorithmic HBM bytes of launch i (SURVEY 8(d) per
+    instance-step x its instances), ipm_ms[i] = its HIP-event duration.  achieved = bytes per launch / average launch duration."""
+    alg, ms = float(np.sum(alg_bytes)), float(np.sum(ipm_ms))
+    ach = alg / (ms * 1e-3) / 1e9
+    traffic = None
+    if traffic_bytes_per_instance_iteration and instance_iterations:
+        traffic = traffic_bytes_per_instance_iteration * instance_iterations / max(len(alg_bytes), 1)
+    return {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+            'traffic': traffic, 'algorithmic_bytes_per_launch': alg / max(len(alg_bytes), 1),
+            'avg_launch_ms': ms / max(len(alg_bytes), 1), 'launches': len(alg_bytes),
+            'note': 'per sub-batch launch INSIDE the closed loop (the streams share the chip): algorithmic bytes / HIP-event duration'}
+
+
 def build_problem():
     from safe_mpc_amd.parser import Parameters
     from safe_mpc_amd.problem import OcpProblem

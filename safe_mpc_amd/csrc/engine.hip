@@ -363,6 +363,10 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         order = h->d_order;
     }
     const int tiles = (int)ev_tiles((size_t)B * (h->N + 1));
+    // experiment knob: the linearisation (+ network pass) and / or the set-up launched once more, to measure what
+    // a stream's chain pays for them inside the loop (bit 0: linearisation, bit 1: set-up)
+    static const int dup = [] { const char* e = getenv("SMPC_DUP_KERNELS"); return e ? atoi(e) : 0; }();
+    if (dup & 1) { if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev, false))) return rc; }
     unsigned long long* wstat = nullptr;
     if (timed && h->timing == 1) {      // (timing mode 2: events only, no in-kernel load-balance probe)
         if (!h->d_wstat) HIPCHK(h, hipMalloc((void**)&h->d_wstat, 4 * sizeof(unsigned long long)));
@@ -376,6 +380,9 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     do {                                                                                                                           \
         hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
                            bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                                  \
+        if (dup & 2)                                                                                                               \
+            hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, \
+                               bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                              \
         if (timed) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                               \
         hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
                            ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active);                                  \

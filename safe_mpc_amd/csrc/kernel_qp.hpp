@@ -17,7 +17,8 @@
 //                 a1 = C^T e1, a2 = C^T e2 (the corrector gradient is gh0 + sigma mu a1 + cw a2)
 //   B2  backward: costate recursion of the corrector with the stored factors (touches neither rows nor Jacobian)
 //   F2  forward : corrector roll-out, ratio test, z+ and c.z+ of every row (B1 rebuilds the row steps from them)
-// Data movement (v8, stores reorganised in v9, factor block packed in v10; the git history and DESIGN.md section 4 have v1-v7 and what each taught):
+// Data movement (v8, stores reorganised in v9, factor block packed in v10, the Jacobian stored once in v11; the git history and DESIGN.md
+// section 4 have v1-v7 and what each taught):
 //   * what a single lane owns -- the bounds, slacks and multipliers of "its" constraint row, its column of [G | rho | I] --
 //     goes from the HBM workspace straight into that lane's registers, re-loaded for the next stage right after its
 //     last use in this one;
@@ -79,8 +80,8 @@ template <int NQ> struct QpLayout {
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
-    int nC;                                                     // doubles of the compact general rows
-    int oC, oIMG, oW, oSL, oPART, oWC, oAUX, oR0, oR1, oR2, oCZA, oCZN;
+    int nJ;                                                     // doubles of the image's Jacobian part [Tt | Gt | gn] (the forward sweeps fetch only this)
+    int oIMG, oW, oSL, oPART, oWC, oAUX, oR0, oR1, oR2, oCZA, oCZN;
     int oZ, oZN, oGH0, oA12;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
@@ -92,16 +93,16 @@ template <int NQ> struct QpLayout {
         iTT = i; i += NZ * NQP;            // torque rows transposed: Tt[c][r]
         iGT = i; i += NQ * MRP;            // collision rows transposed (q columns): Gt[ix][r]
         iGN = i; i += NX;                  // safe-set row
+        nJ = i;                            // (even: NQP, MRP are, and NX = 2 NQ)
         iHQQ = i; i += qp_even_c(NQ * NQ); // cost Hessian (q block) + LM
         iGZ = i; i += NZP;                 // cost gradient
         iB = i; i += NX;                   // dynamics defect
         iSC = i; i += 4;                   // [Huu diagonal, LM on the v diagonal, soft weight, b != 0]
         nIMG = i;                          // (even)
         int o = 0;
-        // general rows without their structural zeros: [torque rows NQ x NZP | collision rows MR x NQP (the q columns) |
-        // safe-set row NX (the x columns)]; the forward sweeps scatter the pieces into a row-major NRC x NZP image in LDS
-        nC = NQ * NZP + MR * NQP + NX;
-        oC = o; o += qp_al8(nC);
+        // (v11: the constraint Jacobian is stored ONCE, in the image's transposed layout; v1-v10 kept a second, row-major copy
+        //  for the forward sweeps -- 160 of a stage's 880 doubles at NQ = 6 -- which now transpose the image's pieces on their way
+        //  into LDS instead)
         oIMG = o; o += qp_al8(nIMG);
         oW = o; o += qp_al8(NWP);         // factor block: columns of [W | w], then the packed columns of L^-1
         oSL = o; o += 16;                  // [soft weight, b != 0, ., . | setup partials: R0, sum lambda t, count, node-0 rows
@@ -465,15 +466,6 @@ __global__ __launch_bounds__(32 * EV_TILE) void k_qp_setup(const smpc_problem_de
     const double bflag = bmax > 0.0 ? 1.0 : 0.0;
 
     // ---- static blocks out ---------------------------------------------------------------------------------------------
-    for (int el = hl; el < Ly.nC; el += 32) {
-        int src;   // position in the row-major image, -1 = padding
-        if (el < NQ * NZP) src = el;
-        else if (el < NQ * NZP + MR * NQP) {
-            const int t = el - NQ * NZP, r = t / NQP, ix = t - r * NQP;
-            src = ix < NQ ? (NQ + r) * NZP + NU + ix : -1;
-        } else src = (NQ + MR) * NZP + NU + (el - NQ * NZP - MR * NQP);
-        stnt_su(src >= 0 ? sC[src] : 0.0, w + Ly.oC + el);
-    }
     if (hl < NRT) stnt_su(dbl2{sLO[hl], sHI[hl]}, reinterpret_cast<dbl2*>(w + Ly.oR0) + hl);
     double* img = w + Ly.oIMG;
     for (int el = hl; el < NZ * NQP; el += 32) {
@@ -605,8 +597,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
     constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
     constexpr int CST_MAX = NRC_MAX * NZP;                                       // row-major image of the general rows in LDS
-    constexpr int NC_MAX = NQ * NZP + MR_MAX * NQP + NX, CST_PF = (NC_MAX / 2 + 31) / 32;   // ... fetched without its zeros
-    static_assert(NQ * NZP / 2 >= 32, "the first piece of every lane lies in the torque rows");
+    constexpr int NJ_MAX = NZ * NQP + NQ * MRP_MAX + NX, CST_PF = (NJ_MAX / 2 + 31) / 32;   // ... fetched as the image's [Tt | Gt | gn]
     constexpr int W_N2 = NWP / 2, WST_PF = (W_N2 + 31) / 32;                 // ... and the factor block
     // (staged in LDS by the other sweeps, in the buffers that only the factorisation sweep uses)
 #ifdef QP_PROFILE
@@ -635,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const ws = ws_all + (size_t)b * Ly.per_instance(N);
     const double dt = D->dt, cB = 0.5 * dt * dt;
     const int img_n2 = Ly.nIMG >> 1;   // 16-byte pieces of the image
-    const int c_n2 = Ly.nC >> 1;            // ... and of the compact general rows
+    const int c_n2 = Ly.nJ >> 1;            // ... and of its Jacobian part (what the forward sweeps fetch)
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
     // [image | D | E | -- buffers of the factorisation sweep only: TD GD Lambda G Wt Hxx P P -- | vectors]
@@ -1172,25 +1163,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             // half-wave, profiles/r02_qp_phase_profile.txt.)
             struct RSet { dbl2 r0, r1, r2; double cza, wc, bi, wsoft; };
             RSet RA, RB;
-            // where piece j of this lane goes in the row-major LDS image (in doubles).  Piece 0 is always in the torque rows,
-            // which the two layouts share; the collision / safe-set pieces move behind their rows' zero u columns.
+            // Where the two entries of piece j of this lane go in the row-major LDS image (offsets in doubles from sIMG): the pieces
+            // come in the image's transposed layout -- Tt[c][r], Gt[ix][r], gn[i] -- and are transposed on their way into LDS (two
+            // 8-byte LDS stores per piece instead of one 16-byte one; the sweeps are bound by the global stream, not by LDS).  Pad
+            // entries of the image go to a cell nobody reads (the image's own LDS area is idle during the forward sweeps).
+            // (both offsets of a piece packed into one register: the kernel has none to spare)
             int cdst[CST_PF];
+            {
+                auto dst_of = [&](int e) -> int {
+                    if (e < NZ * NQP) {
+                        const int c = e / NQP, r = e - c * NQP;
+                        return r < NQ ? O_TD + r * NZP + c : 0;
+                    }
+                    if (e < NZ * NQP + NQ * MRP) {
+                        const int t = e - NZ * NQP, ix = t / max(MRP, 1), r = t - ix * MRP;
+                        return r < MR ? O_TD + (NQ + r) * NZP + NU + ix : 0;
+                    }
+                    return O_TD + (NQ + MR) * NZP + NU + (e - NZ * NQP - NQ * MRP);
+                };
 #pragma unroll
-            for (int j = 0; j < CST_PF; j++) {
-                const int e = 2 * min(hl + 32 * j, c_n2 - 1);
-                int dmap = e;
-                if (e >= NQ * NZP + MR * NQP) dmap = (NQ + MR) * NZP + NU + (e - NQ * NZP - MR * NQP);
-                else if (e >= NQ * NZP) {
-                    const int t = e - NQ * NZP, r = t / NQP;
-                    dmap = (NQ + r) * NZP + NU + (t - r * NQP);
+                for (int j = 0; j < CST_PF; j++) {
+                    const int e = 2 * min(hl + 32 * j, c_n2 - 1);
+                    cdst[j] = dst_of(e) | (dst_of(e + 1) << 16);
                 }
-                cdst[j] = dmap;
             }
             // structural zeros of the image (the factorisation sweep used this LDS for other things): u and v columns of the
             // collision rows, u columns of the safe-set row -- written once per sweep, the stages only refresh the rest
             for (int el = hl; el < NRC * NZP; el += 32) {
                 const int r = el / NZP, c = el - r * NZP;
-                const bool keep = r < NQ || (c >= NU && (c < NU + NQ || (r == NQ + MR && c < NZ)));
+                const bool keep = c < NZ && (r < NQ || (c >= NU && (c < NU + NQ || r == NQ + MR)));   // (what the stages' pieces refresh)
                 if (!keep) sCst[el] = 0.0;
             }
             auto load_w = [&](int k) {
@@ -1205,7 +1206,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             };
             auto load_c = [&](int k) {
                 const double* w = stage_ptr(k);
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oC);
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
 #pragma unroll
                 for (int j = 0; j < CST_PF; j++) Cs[j] = ldnt(s2 + min(hl + 32 * j, c_n2 - 1));
             };
@@ -1245,8 +1246,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 {
 #pragma unroll
                     for (int j = 0; j < CST_PF; j++) {
-                        if constexpr (NQ % 2 == 0) *reinterpret_cast<dbl2*>(sCst + cdst[j]) = Cs[j];   // (NU even: 16-byte aligned)
-                        else { sCst[cdst[j]] = Cs[j].x; sCst[cdst[j] + 1] = Cs[j].y; }
+                        sIMG[cdst[j] & 0xffff] = Cs[j].x;
+                        sIMG[cdst[j] >> 16] = Cs[j].y;
                     }
                 }
                 load_c(kn);

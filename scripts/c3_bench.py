@@ -70,7 +70,23 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 B = sum(g['n'] for g in groups)
 acc = sum(g['acc'].cpu().numpy() for g in groups)
-print(json.dumps({'workload': 'C3: rank %d of 8 of the 32768-instance horizon x alpha grid (N in 20..40, alpha in 20..50), controller %s' % (rank, bench.CONTROLLER),
+
+
+def sync():
+    for g in groups:
+        g['sv'].sync()
+    torch.cuda.synchronize()
+
+
+# per-kernel split of the loop's own launches (a continuation of the loop with the event rings on, outside the timed region) and
+# the roofline block of the dominant kernel: SURVEY 8(d)'s algorithmic bytes per instance-step, by horizon group
+tk = bench.in_loop_kernel_times([g['sv'] for g in groups], step, sync, max(steps, 6))
+names = ['linearise', 'mlp', 'qp_setup', 'qp_ipm', 'solve_total']
+in_loop = {str(g['N']): {n_: float(t_[i]) for i, n_ in enumerate(names)} for g, t_ in zip(groups, tk) if t_ is not None}
+roof = bench.roofline_of_launches([bench.algorithmic_bytes(6, g['N']) * g['n'] for g, t_ in zip(groups, tk) if t_ is not None],
+                                  [t_[3] for t_ in tk if t_ is not None])
+roof['algorithmic_bytes_per_instance_step'] = {str(g['N']): bench.algorithmic_bytes(6, g['N']) for g in groups}
+print(json.dumps({'roofline': roof, 'kernel_ms_in_loop_by_horizon': in_loop,'workload': 'C3: rank %d of 8 of the 32768-instance horizon x alpha grid (N in 20..40, alpha in 20..50), controller %s' % (rank, bench.CONTROLLER),
                   'instances': B, 'groups': {str(g['N']): g['n'] for g in groups}, 'steps': steps, 'warmup': warm,
                   'ms_per_step': 1e3 * dt / steps, 'instance_steps_per_s': B * steps / dt,
                   'mean_ipm_iterations': float(acc[0]) / max(int(acc[2]), 1), 'failed_instance_steps': int(acc[1])}))

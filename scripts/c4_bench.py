@@ -72,7 +72,15 @@ for _ in range(steps):
 sync()
 dt = time.perf_counter() - t0
 acc = sum(g['acc'].cpu().numpy() for g in groups)
-print(json.dumps({'workload': 'C4: 7-DoF Franka-class, N=40, %d instances (one GPU of 8 x 16384), controller %s, sphere + floor rows, NN row on every node' % (B, CONT),
+# per-kernel split of the loop's own launches (a continuation of the loop with the event rings on, outside the timed region) and
+# the roofline block of the dominant kernel: SURVEY 8(d)'s algorithmic bytes per instance-step (15 420 B at 7-DoF, N = 40)
+tk = bench.in_loop_kernel_times([g['sv'] for g in groups], step, sync, max(steps, 6))
+names = ['linearise', 'mlp', 'qp_setup', 'qp_ipm', 'solve_total']
+in_loop = {n_: float(np.mean([t_[i] for t_ in tk if t_ is not None])) for i, n_ in enumerate(names)}
+alg1 = bench.algorithmic_bytes(nq, N)
+roof = bench.roofline_of_launches([alg1 * g['n'] for g, t_ in zip(groups, tk) if t_ is not None], [t_[3] for t_ in tk if t_ is not None])
+roof['algorithmic_bytes_per_instance_step'] = alg1
+print(json.dumps({'roofline': roof, 'kernel_ms_in_loop': in_loop,'workload': 'C4: 7-DoF Franka-class, N=40, %d instances (one GPU of 8 x 16384), controller %s, sphere + floor rows, NN row on every node' % (B, CONT),
                   'instances': B, 'streams': S, 'steps': steps, 'warmup': warm, 'ms_per_step': 1e3 * dt / steps,
                   'instance_steps_per_s': B * steps / dt, 'mean_ipm_iterations': float(acc[0]) / max(int(acc[2]), 1),
                   'failed_instance_steps': int(acc[1]), 'last_step_max_iterations': int(max(int(g['ctrl'].qp_iter.max().item()) for g in groups))}))
