@@ -10,6 +10,7 @@
 
 #include "../../include/smpc.h"
 #include "kernel_qp.hpp"
+#include "kernel_build.hpp"
 #include "kernels_callers.hpp"
 #include "kernels_policy.hpp"
 #include "kernels_mlp.hpp"
@@ -43,6 +44,8 @@ struct smpc_handle {
     // per-batch scratch, grown on demand
     int capB = 0;
     double* d_ev = nullptr;       // linearisation records of the last call, interleaved tiles of EV_TILE nodes (device_model.hpp)
+    double* d_nn = nullptr;       // [B][N+1][1 + nx]: value and gradient of the network's row per node (read by the stage builder)
+    bool ev_new_order[64] = {};   // per slot of the event ring: the solve ran MLP -> stage builder (ev1, ev2 swap their meaning)
     double* d_ws = nullptr;
     size_t ws_bytes = 0;
     int32_t *d_order = nullptr, *d_last_it = nullptr;  // longest-first dispatch order from the previous call's iterations
@@ -152,6 +155,9 @@ int ensure_batch(smpc_handle* h, int B) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if ((rc = dev_alloc(h, &h->d_ev, ev_tiles((size_t)B * (h->N + 1)) * EV_TILE * EV_D))) return rc;
         if ((rc = dev_alloc(h, &h->d_ws, per * (size_t)B))) return rc;
+        if ((rc = dev_alloc(h, &h->d_nn, (size_t)B * (h->N + 1) * (1 + 2 * h->desc.nq)))) return rc;
+        // (entries beyond n_dof_safe_set are never written and must read as zero)
+        HIPCHK(h, hipMemsetAsync(h->d_nn, 0, sizeof(double) * (size_t)B * (h->N + 1) * (1 + 2 * h->desc.nq), h->stream));
         if ((rc = dev_alloc(h, &h->d_order, (size_t)B))) return rc;
         if ((rc = dev_alloc(h, &h->d_last_it, (size_t)B))) return rc;
         h->order_B = 0;
@@ -225,7 +231,7 @@ int ensure_nn_idx(smpc_handle* h, size_t M) {
 // d_p / d_ev: when given and the pass ran as the fused kernel, the chain rule to the node records is done as well and *chained
 // is set (the caller then skips k_nn_chain).
 template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const double* d_x, bool backward, const double* d_p = nullptr,
-                              double* d_ev = nullptr, bool* chained = nullptr) {
+                              double* d_ev = nullptr, bool* chained = nullptr, int compact = 0) {
     int rc;
     if ((rc = ensure_mlp(h, (size_t)M))) return rc;
     const int Mp = (M + 127) / 128 * 128, H = h->H, L = h->nlayers;
@@ -243,10 +249,11 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
             for (int l = 0; l < SMPC_MAX_LAYERS; l++) { Wt.wf[l] = h->d_Wfwd[l]; Wt.wb[l] = h->d_Wbwd[l]; Wt.bias[l] = h->d_bias[l]; }
             const dim3 grd((M + MLPF_ROWS - 1) / MLPF_ROWS), blk(256);
             if (backward)
-                hipLaunchKernelGGL((k_mlp_fused<NQ, true>), grd, blk, 0, s, h->d_desc, M, N, mode, h->act, Wt, d_x, d_p, idx, live, h->d_y, d_ev);
+                hipLaunchKernelGGL((k_mlp_fused<NQ, true>), grd, blk, 0, s, h->d_desc, M, N, mode, h->act, Wt, d_x, d_p, idx, live, h->d_y, d_ev,
+                                   compact);
             else
                 hipLaunchKernelGGL((k_mlp_fused<NQ, false>), grd, blk, 0, s, h->d_desc, M, N, mode, h->act, Wt, d_x, d_p, idx, live, h->d_y,
-                                   (double*)nullptr);
+                                   (double*)nullptr, 0);
             HIPCHK(h, hipGetLastError());
             if (chained) *chained = backward;
             return SMPC_OK;
@@ -290,6 +297,33 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
     return SMPC_OK;
 }
 
+// The network's row (value + gradient w.r.t. the state, chain rule and per-node switch included) of every node that carries it:
+// into the nodes' linearisation records (compact = 0) or into nn[node][1 + nx] (compact = 1, what the stage builder reads).
+template <int NQ>
+int launch_nn(smpc_handle* h, int B, const double* d_xg, const double* d_p, double* d_out, int compact) {
+    if (h->desc.nn_mode == SMPC_NN_NONE) return SMPC_OK;
+    const int N = h->N;
+    hipStream_t s = h->stream;
+    if (h->nlayers == 0) return fail(h, SMPC_ESTATE, "nn_mode != NONE but smpc_set_mlp was not called");
+    // row on every node: only the nodes whose per-node switch is on are evaluated (compacted list, mode 3)
+    const int mode = h->desc.nn_mode == SMPC_NN_TERMINAL ? 1 : 3;
+    const int M = mode == 1 ? B : B * N;
+    int rc;
+    if (mode == 3) {
+        if ((rc = ensure_nn_idx(h, (size_t)M))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
+        hipLaunchKernelGGL(k_nn_compact, dim3((M + 63) / 64), dim3(64), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
+    }
+    bool chained = false;
+    if ((rc = run_mlp<NQ>(h, M, mode, N, d_xg, true, d_p, d_out, &chained, compact))) return rc;
+    if (!chained)
+        hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 63) / 64), dim3(64), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
+                           h->d_y, h->d_GS, d_out, mode == 3 ? h->d_nn_idx : (const int32_t*)nullptr,
+                           mode == 3 ? h->d_nn_cnt : (const int32_t*)nullptr, compact);
+    HIPCHK(h, hipGetLastError());
+    return SMPC_OK;
+}
+
 template <int NQ>
 int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, const double* d_p, double* d_ev, bool timed = false) {
     // (timed: called from launch_solve, which owns the current slot of the event ring; smpc_eval_nodes on its own records nothing --
@@ -301,25 +335,8 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
                        d_p, d_ev);
     HIPCHK(h, hipGetLastError());
     if (timed) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
-    if (h->desc.nn_mode != SMPC_NN_NONE) {
-        if (h->nlayers == 0) return fail(h, SMPC_ESTATE, "nn_mode != NONE but smpc_set_mlp was not called");
-        // row on every node: only the nodes whose per-node switch is on are evaluated (compacted list, mode 3)
-        const int mode = h->desc.nn_mode == SMPC_NN_TERMINAL ? 1 : 3;
-        const int M = mode == 1 ? B : B * N;
-        int rc;
-        if (mode == 3) {
-            if ((rc = ensure_nn_idx(h, (size_t)M))) return rc;
-            HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
-            hipLaunchKernelGGL(k_nn_compact, dim3((M + 63) / 64), dim3(64), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
-        }
-        bool chained = false;
-        if ((rc = run_mlp<NQ>(h, M, mode, N, d_xg, true, d_p, d_ev, &chained))) return rc;
-        if (!chained)
-            hipLaunchKernelGGL((k_nn_chain<NQ>), dim3((M + 63) / 64), dim3(64), 0, s, h->d_desc, M, N, mode, d_xg, d_p,
-                               h->d_y, h->d_GS, d_ev, mode == 3 ? h->d_nn_idx : (const int32_t*)nullptr,
-                               mode == 3 ? h->d_nn_cnt : (const int32_t*)nullptr);
-        HIPCHK(h, hipGetLastError());
-    }
+    int rc;
+    if ((rc = launch_nn<NQ>(h, B, d_xg, d_p, d_ev, 0))) return rc;
     if (timed) HIPCHK(h, hipEventRecord(h->ev_t[2], s));
     return SMPC_OK;
 }
@@ -329,6 +346,67 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
 static size_t qp_pad_lds() {
     static const size_t v = [] { const char* e = getenv("SMPC_QP_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
     return v;
+}
+
+// 1: the lane-cooperative stage builder (kernel_build.hpp: MLP -> k_stage_build -> k_qp_ipm), the default; 0: the thread-per-node
+// kernels of rounds 1-3 (k_node_linearise -> MLP -> k_qp_setup -> k_qp_ipm), kept for A/B runs and as what smpc_eval_nodes uses
+static int stage_build_mode() {
+    static const int v = [] { const char* e = getenv("SMPC_STAGE_BUILD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+// everything of a solve before the interior point: the stage records of the QP workspace, by either path
+template <int NQ>
+int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p, bool timed, int path) {
+    int rc;
+    const bool per_inst = h->inst_B == B;
+    const double* blo = per_inst ? h->d_lo_b : h->d_lo;
+    const double* bhi = per_inst ? h->d_hi_b : h->d_hi;
+    const long bstride = per_inst ? (long)(h->N + 1) * 2 * h->desc.nq : 0L;
+    // experiment knob (DESIGN section 8): the linearisation (+ network pass) and / or the set-up launched once more, to measure what
+    // a stream's chain pays for them inside the loop (bit 0: linearisation, bit 1: set-up; old path only)
+    static const int dup = [] { const char* e = getenv("SMPC_DUP_KERNELS"); return e ? atoi(e) : 0; }();
+    if (path == 1) {
+        if ((rc = launch_nn<NQ>(h, B, xg, p, h->d_nn, 1))) return rc;
+        if (timed) HIPCHK(h, hipEventRecord(h->ev_t[1], h->stream));
+        const long nodes = (long)B * (h->N + 1);
+        const dim3 grd((unsigned)((nodes + 64 / SB_G - 1) / (64 / SB_G))), blk(64);
+        const double* nn = h->desc.nn_mode != SMPC_NN_NONE ? h->d_nn : nullptr;
+#define SMPC_SB_LAUNCH(MR_)                                                                                                       \
+        hipLaunchKernelGGL((k_stage_build<NQ, MR_>), grd, blk, 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi, h->d_zl, nn,     \
+                           h->d_ws, bstride, h->d_active)
+        switch (h->desc.n_rows) {
+        case 6: SMPC_SB_LAUNCH(6); break;
+        case 4: SMPC_SB_LAUNCH(4); break;
+        default: SMPC_SB_LAUNCH(-1); break;
+        }
+#undef SMPC_SB_LAUNCH
+        HIPCHK(h, hipGetLastError());
+        if (timed) { HIPCHK(h, hipEventRecord(h->ev_t[2], h->stream)); HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream)); }
+        return SMPC_OK;
+    }
+    if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev, timed))) return rc;
+    if (dup & 1) { if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev, false))) return rc; }
+    const int tiles = (int)ev_tiles((size_t)B * (h->N + 1));
+    // the row counts of the shipped geometries are compile-time constants of the kernels (6: the reference's six capsule
+    // pairs, config.yaml:205-216; 4: config_fr7.yaml); any other count takes the runtime-row-count instantiation
+#define SMPC_SETUP_LAUNCH(MR_)                                                                                                     \
+    do {                                                                                                                           \
+        hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
+                           bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                                  \
+        if (dup & 2)                                                                                                               \
+            hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, \
+                               bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                              \
+    } while (0)
+    switch (h->desc.n_rows) {
+    case 6: SMPC_SETUP_LAUNCH(6); break;
+    case 4: SMPC_SETUP_LAUNCH(4); break;
+    default: SMPC_SETUP_LAUNCH(-1); break;
+    }
+#undef SMPC_SETUP_LAUNCH
+    HIPCHK(h, hipGetLastError());
+    if (timed) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));
+    return SMPC_OK;
 }
 
 template <int NQ>
@@ -343,30 +421,21 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         h->timing_now = cs == hipStreamCaptureStatusNone;
     }
     const bool timed = h->timing_now;
+    const int path = stage_build_mode();
     if (timed) {
         h->ev_cur = (h->ev_cur + 1) % smpc_handle::EV_RING;
         h->ev_t = h->ev_sets[h->ev_cur];
         h->ev_complete[h->ev_cur] = false;      // (an error return below leaves the slot invalid, not stale)
+        h->ev_new_order[h->ev_cur] = path == 1;
         h->timed_count++;
         HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
     }
-    if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev, timed))) return rc;
-    // fast path: the row count of the reference's default geometry (6 capsule pairs, config.yaml:205-216) is a
-    // compile-time constant of the kernel; any other geometry takes the runtime-row-count instantiation
-    const bool per_inst = h->inst_B == B;
-    const double* blo = per_inst ? h->d_lo_b : h->d_lo;
-    const double* bhi = per_inst ? h->d_hi_b : h->d_hi;
-    const long bstride = per_inst ? (long)(h->N + 1) * 2 * h->desc.nq : 0L;
+    if ((rc = launch_stage_records<NQ>(h, B, x0, xg, ug, p, timed, path))) return rc;
     const int32_t* order = nullptr;
     if (h->order_B == B && B > 1) {
         hipLaunchKernelGGL(k_order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->d_last_it, h->d_order);
         order = h->d_order;
     }
-    const int tiles = (int)ev_tiles((size_t)B * (h->N + 1));
-    // experiment knob (DESIGN section 8): the linearisation (+ network pass) and / or the set-up launched once more, to measure what
-    // a stream's chain pays for them inside the loop (bit 0: linearisation, bit 1: set-up)
-    static const int dup = [] { const char* e = getenv("SMPC_DUP_KERNELS"); return e ? atoi(e) : 0; }();
-    if (dup & 1) { if ((rc = launch_eval<NQ>(h, B, xg, ug, p, h->d_ev, false))) return rc; }
     unsigned long long* wstat = nullptr;
     if (timed && h->timing == 1) {      // (timing mode 2: events only, no in-kernel load-balance probe)
         if (!h->d_wstat) HIPCHK(h, hipMalloc((void**)&h->d_wstat, 4 * sizeof(unsigned long long)));
@@ -374,19 +443,9 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         HIPCHK(h, hipMemcpyAsync(h->d_wstat, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
         wstat = h->d_wstat;
     }
-    // the row counts of the shipped geometries are compile-time constants of the kernels (6: the reference's six capsule
-    // pairs, config.yaml:205-216; 4: config_fr7.yaml); any other count takes the runtime-row-count instantiation
 #define SMPC_QP_LAUNCH(MR_)                                                                                                        \
-    do {                                                                                                                           \
-        hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo,     \
-                           bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                                  \
-        if (dup & 2)                                                                                                               \
-            hipLaunchKernelGGL((k_qp_setup<NQ, MR_>), dim3(tiles), dim3(32 * EV_TILE), 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, \
-                               bhi, h->d_zl, h->d_ev, h->d_ws, bstride, h->d_active);                                              \
-        if (timed) HIPCHK(h, hipEventRecord(h->ev_t[4], h->stream));                                                               \
-        hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,   \
-                           ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active);                                  \
-    } while (0)
+    hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,       \
+                       ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active)
     switch (h->desc.n_rows) {
     case 6: SMPC_QP_LAUNCH(6); break;
     case 4: SMPC_QP_LAUNCH(4); break;
@@ -584,7 +643,7 @@ void smpc_destroy(smpc_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    void* ptrs[] = {h->d_desc, h->d_zl, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
+    void* ptrs[] = {h->d_desc, h->d_zl, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_nn, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
                     h->d_st, h->d_it, h->d_S, h->d_y, h->d_GS, h->d_dA, h->d_dB, h->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < SMPC_MAX_LAYERS; l++) {
@@ -1236,8 +1295,10 @@ int smpc_get_timing(smpc_handle* h, float* ms4) {
     if (!h->timed || !h->ev_complete[h->ev_cur]) return fail(h, SMPC_ESTATE, "no solve has been timed since smpc_enable_timing");
     (void)hipSetDevice(h->device);
     HIPCHK(h, hipEventSynchronize(h->ev_t[3]));
-    HIPCHK(h, hipEventElapsedTime(&ms4[0], h->ev_t[0], h->ev_t[1]));
-    HIPCHK(h, hipEventElapsedTime(&ms4[1], h->ev_t[1], h->ev_t[2]));
+    // (stage-builder path: the network pass comes first, ev0 -> ev1, then linearisation + set-up in one kernel, ev1 -> ev2)
+    const bool nw = h->ev_new_order[h->ev_cur];
+    HIPCHK(h, hipEventElapsedTime(&ms4[nw ? 1 : 0], h->ev_t[0], h->ev_t[1]));
+    HIPCHK(h, hipEventElapsedTime(&ms4[nw ? 0 : 1], h->ev_t[1], h->ev_t[2]));
     HIPCHK(h, hipEventElapsedTime(&ms4[2], h->ev_t[2], h->ev_t[3]));
     HIPCHK(h, hipEventElapsedTime(&ms4[3], h->ev_t[0], h->ev_t[3]));
     return SMPC_OK;
@@ -1263,8 +1324,9 @@ int smpc_get_timing_history(smpc_handle* h, int back, float* ms6) {
     if (!h->ev_complete[slot]) return SMPC_OK;     // the solve that owns the slot returned early: valid stays 0
     hipEvent_t* ev = h->ev_sets[slot];
     if (hipEventQuery(ev[3]) != hipSuccess) { (void)hipGetLastError(); return SMPC_OK; }   // not finished yet: valid stays 0
-    HIPCHK(h, hipEventElapsedTime(&ms6[0], ev[0], ev[1]));
-    HIPCHK(h, hipEventElapsedTime(&ms6[1], ev[1], ev[2]));
+    const bool nw = h->ev_new_order[slot];
+    HIPCHK(h, hipEventElapsedTime(&ms6[nw ? 1 : 0], ev[0], ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&ms6[nw ? 0 : 1], ev[1], ev[2]));
     HIPCHK(h, hipEventElapsedTime(&ms6[2], ev[2], ev[4]));
     HIPCHK(h, hipEventElapsedTime(&ms6[3], ev[4], ev[3]));
     HIPCHK(h, hipEventElapsedTime(&ms6[4], ev[0], ev[3]));
@@ -1297,6 +1359,41 @@ int smpc_get_qp_wave_stats(smpc_handle* h, double* out3) {
 }
 
 }  // extern "C"
+
+// Test hook (not part of include/smpc.h): the stage records of the QP workspace as either path builds them (path 1: MLP ->
+// k_stage_build; path 0: k_node_linearise -> MLP -> k_qp_setup), copied to the host, and the layout's offsets -- so that
+// tests/test_gpu_parity.py can compare the two builders block by block.  Host pointers.  layout[16] = {stride, nIMG, oIMG, oSL,
+// oAUX, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, doubles per instance, 0}.
+extern "C" int smpc_debug_stage_records(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
+                                        int path, double* ws_out, int32_t* layout) {
+    if (!h || B <= 0 || !x0 || !xg || !ug || !p || !ws_out || !layout) return SMPC_EINVAL;
+    (void)hipSetDevice(h->device);
+    int rc;
+    if ((rc = ensure_batch(h, B)) || (rc = ensure_io(h, B))) return rc;
+    const int N = h->N, nx = 2 * h->desc.nq, nu = h->desc.nq;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_x0, x0, sizeof(double) * B * nx, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_xg, xg, sizeof(double) * B * (N + 1) * nx, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_ug, ug, sizeof(double) * B * N * nu, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_p, p, sizeof(double) * B * (N + 1) * SMPC_NP, hipMemcpyHostToDevice, s));
+    const size_t per = ws_doubles_per_instance(h->desc, N);
+    HIPCHK(h, hipMemsetAsync(h->d_ws, 0, per * (size_t)B * sizeof(double), s));
+    DISPATCH_NQ(h, (launch_stage_records<NQ_>(h, B, h->d_x0, h->d_xg, h->d_ug, h->d_p, false, path)));
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(ws_out, h->d_ws, per * (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    auto fill = [&](auto Ly) {
+        const int v[16] = {Ly.stride, Ly.nIMG, Ly.oIMG, Ly.oSL, Ly.oAUX, Ly.oR0, Ly.oR1, Ly.oR2, Ly.oCZA, Ly.oCZN, Ly.oZ, Ly.oZN, Ly.NRT, Ly.nJ,
+                           (int)per, 0};
+        for (int i = 0; i < 16; i++) layout[i] = v[i];
+    };
+    switch (h->desc.nq) {
+    case 5: fill(QpLayout<5>(h->desc.n_rows)); break;
+    case 6: fill(QpLayout<6>(h->desc.n_rows)); break;
+    default: fill(QpLayout<7>(h->desc.n_rows)); break;
+    }
+    return SMPC_OK;
+}
 
 #ifdef QP_PROFILE
 // diagnostic builds only (not part of include/smpc.h): per-phase shader-clock sums of k_qp_ipm since the last call

@@ -283,14 +283,18 @@ template <int NQ>
 __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N, int mode,
                            const double* __restrict__ xg, const double* __restrict__ p, const float* __restrict__ y,
                            const float* __restrict__ GS, double* __restrict__ out, const int32_t* __restrict__ idx,
-                           const int32_t* __restrict__ m_live) {
+                           const int32_t* __restrict__ m_live, int compact) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     if (m_live && m >= *m_live) return;
     const long node = nn_row_to_node(mode, N, m, idx);
     const double* x = xg + node * (2 * NQ);
     const double* pk = p + node * SMPC_NP;
-    double* const o = ev_node(out, node);          // (interleaved tile: element f at o[f * EV_TILE])
+    // compact: out is nn[node][1 + 2 NQ] = (value, gradient) -- what k_stage_build / the QP's stage builder read; otherwise the
+    // node's linearisation record (interleaved tile: element f at o[f * EV_TILE])
+    double* const o = compact ? out + node * (1 + 2 * NQ) : ev_node(out, node);
+    const long es = compact ? 1 : EV_TILE;
+    const int o_val = compact ? 0 : SMPC_EV_OFF(nn_val), o_grad = compact ? 1 : SMPC_EV_OFF(nn_grad);
     if (!(pk[4] > 0.0)) return;  // switched off: row sits mid-bounds, leave (0, 0)
     const int nd = D->nn_dof;
     const float* gs = GS + (size_t)m * MLP_NPAD;
@@ -305,12 +309,12 @@ __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N
     for (int i = 0; i < NQ; i++)
         if (i < nd) gdv += (double)gs[nd + i] * v[i];
     const double kap = (100.0 - pk[3]) / 100.0;
-    o[SMPC_EV_OFF(nn_val) * EV_TILE] = (double)y[m] * kap - vn;
+    o[o_val * es] = (double)y[m] * kap - vn;
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
         if (i < nd) {
-            o[(SMPC_EV_OFF(nn_grad) + i) * EV_TILE] = kap * (double)gs[i] / D->nn_std[i];
-            o[(SMPC_EV_OFF(nn_grad) + NQ + i) * EV_TILE] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
+            o[(o_grad + i) * es] = kap * (double)gs[i] / D->nn_std[i];
+            o[(o_grad + NQ + i) * es] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
         }
     }
 }
@@ -336,7 +340,7 @@ template <int NQ, bool BWD>
 __global__ __launch_bounds__(256) void k_mlp_fused(const smpc_problem_desc* __restrict__ D, int M, int N, int mode, int act,
                                                    MlpWeights Wt, const double* __restrict__ xg, const double* __restrict__ p,
                                                    const int32_t* __restrict__ idx, const int32_t* __restrict__ m_live,
-                                                   float* __restrict__ y_out, double* __restrict__ ev_out) {
+                                                   float* __restrict__ y_out, double* __restrict__ ev_out, int compact) {
     constexpr int H = MLPF_H, LD = MLPF_LD, R = MLPF_ROWS;
     __shared__ __attribute__((aligned(16))) float bufA[R * LD];
     __shared__ __attribute__((aligned(16))) float bufB[R * LD];
@@ -517,7 +521,9 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const smpc_problem_desc* __re
         const double* x = xg + node * (2 * NQ);
         const double* pk = p + node * SMPC_NP;
         if (pk[4] > 0.0) {                                   // (switched off: the row sits mid-bounds, (0, 0) is left)
-            double* const o = ev_node(ev_out, node);
+            double* const o = compact ? ev_out + node * (1 + 2 * NQ) : ev_node(ev_out, node);      // (see k_nn_chain)
+            const long es = compact ? 1 : EV_TILE;
+            const int o_val = compact ? 0 : SMPC_EV_OFF(nn_val), o_grad = compact ? 1 : SMPC_EV_OFF(nn_grad);
             const int nd = D->nn_dof;
             float gs[MLP_KPAD];
 #pragma unroll
@@ -533,12 +539,12 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const smpc_problem_desc* __re
             for (int i = 0; i < NQ; i++)
                 if (i < nd) gdv += (double)gs[nd + i] * v[i];
             const double kap = (100.0 - pk[3]) / 100.0;
-            o[SMPC_EV_OFF(nn_val) * EV_TILE] = (double)sy[t] * kap - vn;
+            o[o_val * es] = (double)sy[t] * kap - vn;
 #pragma unroll
             for (int i = 0; i < NQ; i++)
                 if (i < nd) {
-                    o[(SMPC_EV_OFF(nn_grad) + i) * EV_TILE] = kap * (double)gs[i] / D->nn_std[i];
-                    o[(SMPC_EV_OFF(nn_grad) + NQ + i) * EV_TILE] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
+                    o[(o_grad + i) * es] = kap * (double)gs[i] / D->nn_std[i];
+                    o[(o_grad + NQ + i) * es] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
                 }
         }
     }

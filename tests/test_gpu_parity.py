@@ -286,6 +286,107 @@ def test_kernel_instantiations_and_odd_batches(nq, B, drop_rows):
     assert np.abs(xa[ok] - xb[ok]).max() < 1e-4
 
 
+def _stage_records(s, x0, xg, ug, p, path):
+    """the QP workspace after the stage records are built (no interior point), by either builder: test hook of the engine"""
+    import ctypes as C
+    L = s.L
+    L.smpc_debug_stage_records.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p]
+    lay = np.zeros(16, np.int32)
+    B = x0.shape[0]
+    # (first call with a one-element buffer only to learn the size)
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (x0, xg, ug, p)]
+    from safe_mpc_amd.problem import OcpProblem  # noqa: F401
+    probe = np.zeros(1)
+    per = None
+    for _ in range(2):
+        out = probe if per is None else np.zeros((B, per))
+        if per is None:
+            # learn the layout from a B = 1 call into a generous buffer
+            out = np.zeros(64 * 2048)
+            rc = L.smpc_debug_stage_records(s.h, 1, *[a[:1].ctypes.data for a in arrs], path, out.ctypes.data, lay.ctypes.data)
+            assert rc == 0, L.smpc_last_error(s.h)
+            per = int(lay[14])
+            assert per <= out.size
+            continue
+        rc = L.smpc_debug_stage_records(s.h, B, *[a.ctypes.data for a in arrs], path, out.ctypes.data, lay.ctypes.data)
+        assert rc == 0, L.smpc_last_error(s.h)
+    return out, lay
+
+
+@pytest.mark.parametrize('case', ['st', 'constraint_everywhere', 'zerovel_nls', 'receding_flags', 'real_receding_tubes', 'fr7', 'nq5',
+                                  'rows12', 'rows0', 'backup_zero_cost'])
+def test_stage_builder_equals_thread_per_node_kernels(case):
+    """Round 4: the lane-cooperative stage builder (kernel_build.hpp: k_stage_build, linearisation + QP set-up in one pass, 8
+    lanes per node) against the thread-per-node kernels of rounds 1-3 (k_node_linearise -> k_qp_setup), block by block of the
+    stage record: Jacobian image, cost blocks, defect, bounds, initial slacks / multipliers, start vectors, the stage's partial
+    sums.  Same formulas, different distribution and summation order: 1e-11 relative to each block's scale.  (The thread-per-node
+    path is itself pinned to the oracle at 1e-9 by test_eval_nodes_parity; the solves below it run through the builder.)"""
+    from conftest import make_problem_fr7
+    N = 12
+    kw = {}
+    if case == 'fr7':
+        par, prob, net = make_problem_fr7(N=16)
+        N = 16
+    elif case == 'zerovel_nls':
+        par, prob, net = make_problem('zerovel', 'nls', N=N)
+    elif case == 'backup_zero_cost':
+        par, prob, net = make_problem('backup', 'zero', N=N)
+    elif case == 'nq5':
+        par, prob, net = make_problem('st', 'ext', N=N, nq=5)
+    elif case in ('rows12', 'rows0'):
+        par, prob, net = make_problem('st', 'ext', N=N)
+        x0_pre = sample_instances(prob, 11, seed=3, vel_scale=0.3)       # (sampled against the unmodified geometry)
+        if case == 'rows0':
+            prob.desc.n_rows = 0
+        else:
+            n0 = prob.desc.n_rows
+            for r in range(6):
+                src, dst = prob.desc.rows[r % n0], prob.desc.rows[n0 + r]
+                for f, _ in type(src)._fields_:
+                    setattr(dst, f, getattr(src, f))
+                dst.lb = 0.6 * src.lb
+            prob.desc.n_rows = 12
+    else:
+        name = {'receding_flags': 'receding', 'real_receding_tubes': 'real_receding'}.get(case, case)
+        par, prob, net = make_problem(name, 'ext', N=N)
+    B = 11
+    s = _solver(prob, net)
+    x0 = x0_pre if case in ('rows12', 'rows0') else sample_instances(prob, B, seed=3, vel_scale=0.3)
+    xg, ug, p = constant_guess(prob, x0)
+    rng = np.random.default_rng(2)
+    ug += rng.uniform(-3, 3, ug.shape)
+    xg = s.guess_correction(xg, ug)
+    xg[:, 1:] += 0.01 * rng.standard_normal(xg[:, 1:].shape)          # a dynamics defect
+    x0 = x0 + 0.003 * rng.standard_normal(x0.shape)                   # dx_0 != 0
+    if case == 'receding_flags':
+        p[:, :, 4] = np.where(rng.uniform(size=p.shape[:2]) < 0.5, 1.0, -1.0)
+        s.set_slack_weights(np.concatenate([[0.0], rng.choice([0.0, 1e2, 1e4], N)]))
+    if case == 'real_receding_tubes':
+        lo = np.broadcast_to(prob.x_min, (B, N + 1, prob.nx)).copy()
+        hi = np.broadcast_to(prob.x_max, (B, N + 1, prob.nx)).copy()
+        lo[:, N], hi[:, N] = prob.lbx_e, prob.ubx_e
+        for b in range(B):
+            r = 1 + b % (N - 1)
+            lo[b, r], hi[b, r] = xg[b, r + 1] - 1e-3, xg[b, r + 1] + 1e-3
+        s.set_instance_bounds(lo, hi)
+    new, lay = _stage_records(s, x0, xg, ug, p, 1)
+    old, lay2 = _stage_records(s, x0, xg, ug, p, 0)
+    assert np.array_equal(lay, lay2)
+    stride, nIMG, oIMG, oSL, oAUX, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, per = [int(v) for v in lay[:15]]
+    new, old = new.reshape(B, N + 1, stride), old.reshape(B, N + 1, stride)
+    blocks = {'jacobian': (oIMG, nJ), 'cost / defect / scalars': (oIMG + nJ, nIMG - nJ), 'scalars + partial sums + w': (oSL, 16),
+              'aux': (oAUX, 2 * prob.nx), 'bounds': (oR0, 2 * NRT), 'slacks': (oR1, 2 * NRT), 'multipliers': (oR2, 2 * NRT),
+              'c.z_aff': (oCZA, 32), 'c.z+': (oCZN, 32), 'z': (oZ, 3 * prob.nq), 'z+': (oZN, 3 * prob.nq)}
+    for name, (o, n) in blocks.items():
+        a, b = new[:, :, o:o + n], old[:, :, o:o + n]
+        big = np.abs(b) >= 1e299                                 # the "absent" sentinel
+        assert np.array_equal(np.abs(a) >= 1e299, big), name
+        a, b = np.where(big, 0.0, a), np.where(big, 0.0, b)
+        scale = np.abs(b).max() + 1e-300
+        assert np.abs(a - b).max() <= 1e-11 * scale + 1e-13, (case, name, np.abs(a - b).max(), scale)
+    assert np.abs(old[:, :, oIMG:oIMG + nJ]).max() > 0
+
+
 @pytest.mark.parametrize('N', [1, 2, 3, 63])
 def test_horizon_extremes(N):
     """Shortest horizons (the unrolled / look-ahead loops of the QP kernel degenerate) and SMPC_MAX_N."""
