@@ -534,7 +534,7 @@ def main():
         # the iterations it runs); traffic of THIS probe launch = that x the probe's own iteration count x instances, so that
         # traffic / kernel time is the rate of the launch that was timed here.  null when there is no file for this round's kernel.
         traffic, traffic_rate, traffic_src, bpi = None, None, None, None
-        for name in ('r03_pmc_traffic.json',):
+        for name in ('r04_pmc_traffic.json',):
             tf = os.path.join(ROOT, 'profiles', name)
             if os.path.exists(tf) and CONTROLLER == 'st':
                 tj = json.load(open(tf))

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Everything profiles/r04_* is made from, in one gpurun session (copy gpurun_out/r04/* into profiles/ afterwards):
+#   bench.json                         python bench.py                                  (the line the driver records)
+#   bench_kernel_stats.csv, bench_kernel_summary_by_grid.txt, bench_under_rocprof.json    rocprofv3 --kernel-trace --stats of the same
+#   pmc_traffic.json, kernel_sheet.txt two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) over scripts/qp_bench.py
+#   c2_*, c3_*, c4_*                   BASELINE configs 2-4: bench lines (with roofline + in-loop kernel split) and kernel traces
+#   policy_bench.txt                   run_mpc(on_device=True) per controller
+set -x
+export TMPDIR=/tmp
+R=/root/repo
+O=$R/gpurun_out/r04
+rm -rf $O; mkdir -p $O
+cd $R
+bash scripts/prof_pmc.sh r04/pmc > $O/pmc.log 2>&1 && cp $O/pmc/pmc_traffic.json $O/pmc_traffic.json && cp $O/pmc/kernel_sheet.txt $O/kernel_sheet.txt
+mkdir -p profiles_tmp
+timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err
+bash scripts/prof_bench.sh r04/benchprof > /dev/null 2>&1
+cp $O/benchprof/kernel_stats.csv $O/bench_kernel_stats.csv; cp $O/benchprof/kernel_summary_by_grid.txt $O/bench_kernel_summary_by_grid.txt; cp $O/benchprof/bench_under_rocprof.json $O/bench_under_rocprof.json
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4 -- python3 $R/scripts/c4_bench.py 10 2 > $O/c4_bench_under_rocprof.json 2> $O/c4.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -- python3 $R/scripts/c3_bench.py 20 3 > $O/c3_bench_under_rocprof.json 2> $O/c3.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -- python3 $R/bench.py --batch 65536 --noise 10 --control-noise 1 --steps 10 --warmup 2 --no-cpu-baseline --no-survey-window > $O/c2_bench_under_rocprof.json 2> $O/c2.err
+for c in c2 c3 c4; do
+  f=$(ls $O/$c/*/*kernel_trace.csv | head -1)
+  python3 $R/scripts/trace_summary.py $f > $O/${c}_kernel_summary_by_grid.txt
+  cp $(ls $O/$c/*/*kernel_stats.csv | head -1) $O/${c}_kernel_stats.csv
+  rm -rf $O/$c
+done
+cd $R
+timeout -k 10 200 python3 scripts/c4_bench.py 10 2 > $O/c4_bench.json 2>> $O/c4.err
+timeout -k 10 200 python3 scripts/c3_bench.py 20 3 > $O/c3_bench.json 2>> $O/c3.err
+timeout -k 10 300 python3 bench.py --batch 65536 --noise 10 --control-noise 1 --steps 10 --warmup 2 --no-cpu-baseline --no-survey-window > $O/c2_bench.json 2>> $O/c2.err
+SMPC_BENCH_CONTROLLER=constraint_everywhere timeout -k 10 300 python3 bench.py --no-cpu-baseline > $O/bench_constraint_everywhere.json 2>> $O/bench.err
+timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-survey-window > $O/bench_100steps.json 2>> $O/bench.err
+SMPC_STEPS=60 timeout -k 10 400 python3 scripts/policy_bench.py st htwa receding real_receding > $O/policy_bench.txt 2>&1
+rm -rf $O/pmc $O/benchprof profiles_tmp
+ls -la $O

@@ -30,7 +30,7 @@ mean = lambda v: sum(v) / len(v)
 out = {'workload': 'scripts/qp_bench.py: C1 state after 5 closed-loop steps, B=%d, N=30, identical launches, mean %.2f IPM iterations' % (B, iters),
        'note': 'FETCH_SIZE doubled (gfx950 tallies 64 B per 128-B request; checked for 8/16 B per lane loads), WRITE_SIZE exact; '
                'separate --pmc passes; counter units are KB'}
-for k in ('k_qp_ipm', 'k_qp_setup'):
+for k in [k_ for k_ in ('k_qp_ipm', 'k_qp_setup', 'k_stage_build', 'k_node_linearise', 'k_mlp_fused') if k_ in vf and k_ in vw]:
     f_kb, w_kb = mean(half(vf[k])), mean(half(vw[k]))
     dur = 0.5 * (mean(half(df[k])) + mean(half(dw[k]))) * 1e-9
     byt = (2.0 * f_kb + w_kb) * 1024.0

@@ -933,7 +933,11 @@ def test_late_closed_loop_qps_against_independent_dense_solver(controller):
       (a) engine == oracle on the same late QP at the RTI tolerance (same algorithm, rounding-different paths);
       (b) the engine's step is feasible for the dense QP and its objective is within the duality-gap bound of the dense optimum;
       (c) the measured gap in the controls at the default exit stays below 5e-2 (the softness, stated);
-      (d) with the exit tightened to 1e-12 the engine's step converges to the dense solver's optimum: 5e-4 (1 + |v*|)."""
+      (d) with the exit tightened to 1e-12 the engine's step converges to the dense solver's optimum: 2e-3 (1 + |v*|).
+    (c) and (d) follow the bound the flat directions allow: an objective gap <= m x tol over a Hessian whose smallest eigenvalue is
+    LM x dt = 2.5e-3 leaves |dz| <= sqrt(2 m tol / 2.5e-3): ~0.1 at tol = 1e-8 (m ~ 1300 complementarity pairs), ~1e-3 at 1e-12;
+    measured over the loops of rounds 3-4: 1e-2 and 2e-4 .. 8e-4 -- which instance shows the largest gap changes with rounding-level
+    changes of the linearisation (the builder of round 4 moved it from 1.8e-4 to 8.1e-4)."""
     from qp_ref import condense, solve_condensed
     N, B = 30, 12
     par, prob, net = make_problem(controller, 'ext', N=N)
@@ -975,7 +979,7 @@ def test_late_closed_loop_qps_against_independent_dense_solver(controller):
                 g0 = np.abs(du - v).max() / (1 + np.abs(v).max())
                 g1 = np.abs(dq - v).max() / (1 + np.abs(v).max())
                 assert g0 < 5e-2, (j, b, g0)                                                                  # (c)
-                assert g1 < 5e-4, (j, b, g1)                                                                  # (d)
+                assert g1 < 2e-3, (j, b, g1)                                                                  # (d)
                 worst['gap_default'], worst['gap_tight'] = max(worst['gap_default'], g0), max(worst['gap_tight'], g1)
                 worst['obj'] = max(worst['obj'], gap / (1 + abs(obj(v))))
                 checked += 1
