@@ -362,13 +362,16 @@ int smpc_sync(smpc_handle* h);
 /* the hipStream_t the handle enqueues on (for event timing by the caller) */
 void* smpc_stream(smpc_handle* h);
 /* device time of the kernels of the last smpc_solve_batch, measured with HIP events on the handle's stream:
- * ms[0] linearise, ms[1] MLP, ms[2] QP, ms[3] total.  Mirrors ocp_solver.get_stats('time_lin'|'time_qp'|'time_tot')
+ * ms[0] linearise (since round 4: the stage builder -- linearisation AND the set-up of the QP's stage records, one kernel),
+ * ms[1] MLP, ms[2] QP (the interior point; with SMPC_STAGE_BUILD=0 also k_qp_setup), ms[3] total.
+ * Mirrors ocp_solver.get_stats('time_lin'|'time_qp'|'time_tot')
  * (controller.py:123-124,192-193).  Only valid when timing was enabled.  on = 1: HIP events + the in-kernel load-balance probe of
  * smpc_get_qp_wave_stats; on = 2: HIP events only (what a running loop can afford); 0: off. */
 int smpc_enable_timing(smpc_handle* h, int on);
 int smpc_get_timing(smpc_handle* h, float* ms4);
-/* Split of ms[2] of smpc_get_timing: ms2[0] = k_qp_setup (stage records + initial point), ms2[1] = k_qp_ipm (the interior-
- * point iterations) -- the per-kernel durations rocprofv3 --kernel-trace reports (acados: time_qp_solver_call). */
+/* Split of ms[2] of smpc_get_timing: ms2[0] = k_qp_setup (stage records + initial point; ~0 on the default path, where the stage
+ * builder has already written them), ms2[1] = k_qp_ipm (the interior-point iterations) -- the per-kernel durations rocprofv3
+ * --kernel-trace reports (acados: time_qp_solver_call). */
 int smpc_get_qp_timing(smpc_handle* h, float* ms2);
 /* The same durations for the solve `back` solves before the last one (0 = the last; the handle keeps the events of its last 64
  * timed solves), without waiting: ms6 = {linearise, MLP, k_qp_setup, k_qp_ipm, total, valid}.  valid = 0 (and the rest 0) when

@@ -190,3 +190,44 @@ def test_double_integrator_closed_form(z1):
         v = x0[6:] + dt * ug[0, :k].sum(0)
         q = x0[:6] + k * dt * x0[6:] + dt ** 2 * sum((k - j - 0.5) * ug[0, j] for j in range(k))
         assert np.allclose(out[k, :6], q, atol=1e-13) and np.allclose(out[k, 6:], v, atol=1e-13)
+
+
+def test_momentum_operator_closed_form_used_by_the_stage_builder():
+    """kernel_build.hpp (round 4) replaces the 36-entry momentum operator of rnea_deriv.hpp,
+        B m = Y (m x v) + m x* (Y v) + v x* (Y m),
+    by its closed form with 12 numbers: with v = (w; u), h = Y v = (n; f), m = (a; l):  B m = (Baa a ; -2 f x a),
+    Baa = [w]x I - I [w]x - [n]x - (u mc^T + mc u^T - 2 (mc . u) 1); the blocks acting on l vanish identically.  Checked here
+    against the column-by-column definition for random bodies and motions (the GPU test compares the two kernels' outputs)."""
+    rng = np.random.default_rng(7)
+
+    def sk(x):
+        return np.array([[0, -x[2], x[1]], [x[2], 0, -x[0]], [-x[1], x[0], 0]])
+    for _ in range(20):
+        m = rng.uniform(0.2, 5.0)
+        c = rng.normal(size=3)
+        mc = m * c
+        A = rng.normal(size=(3, 3))
+        Io = A @ A.T + m * (c @ c * np.eye(3) - np.outer(c, c))          # rotational inertia about the origin
+
+        def Y(v):
+            a, l = v[:3], v[3:]
+            return np.concatenate([Io @ a + np.cross(mc, l), m * l + np.cross(a, mc)])
+
+        def mxm(m1, m2):
+            return np.concatenate([np.cross(m1[:3], m2[:3]), np.cross(m1[:3], m2[3:]) + np.cross(m1[3:], m2[:3])])
+
+        def mxf(mv, f):
+            return np.concatenate([np.cross(mv[:3], f[:3]) + np.cross(mv[3:], f[3:]), np.cross(mv[:3], f[3:])])
+        v = rng.normal(size=6)
+        h = Y(v)
+        B = np.zeros((6, 6))
+        for k in range(6):
+            e = np.zeros(6)
+            e[k] = 1.0
+            B[:, k] = Y(mxm(e, v)) + mxf(e, h) + mxf(v, Y(e))
+        w, u, n, f = v[:3], v[3:], h[:3], h[3:]
+        Baa = sk(w) @ Io - Io @ sk(w) - sk(n) - (np.outer(u, mc) + np.outer(mc, u) - 2.0 * (mc @ u) * np.eye(3))
+        scale = np.abs(B).max()
+        assert np.abs(B[:3, :3] - Baa).max() < 1e-13 * scale
+        assert np.abs(B[:3, 3:]).max() < 1e-13 * scale and np.abs(B[3:, 3:]).max() < 1e-13 * scale
+        assert np.abs(B[3:, :3] + 2.0 * sk(f)).max() < 1e-13 * scale
