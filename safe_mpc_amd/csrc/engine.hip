@@ -372,8 +372,10 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
         const long nodes = (long)B * (h->N + 1);
         const dim3 grd((unsigned)((nodes + 64 / SB_G - 1) / (64 / SB_G))), blk(64);
         const double* nn = h->desc.nn_mode != SMPC_NN_NONE ? h->d_nn : nullptr;
+        // (experiment knob: extra dynamic LDS per block of the builder -- how much its start depends on LDS room next to QP wavefronts)
+        static const size_t sb_pad = [] { const char* e = getenv("SMPC_SB_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
 #define SMPC_SB_LAUNCH(MR_)                                                                                                       \
-        hipLaunchKernelGGL((k_stage_build<NQ, MR_>), grd, blk, 0, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi, h->d_zl, nn,     \
+        hipLaunchKernelGGL((k_stage_build<NQ, MR_>), grd, blk, sb_pad, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi, h->d_zl, nn,     \
                            h->d_ws, bstride, h->d_active)
         switch (h->desc.n_rows) {
         case 6: SMPC_SB_LAUNCH(6); break;

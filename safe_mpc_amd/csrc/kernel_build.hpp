@@ -18,10 +18,13 @@
 //                 operator B_g and force f_g; a suffix scan over the lanes (wave shuffles) makes them the composites Yc_g, Bc_g, F_g;
 //                 lane m then walks k = 0..m with S_k, psi_k, chi_k of the other joints from LDS and fills row m (k < m) and
 //                 column m (j <= m) of M, dtau/dq, dtau/dqd -- written into the stage image's transposed Jacobian Tt[c][r] in LDS
-//   S  set-up     rows distributed over the 8 lanes (row r on lane r mod 8): bounds, initial slacks and multipliers, the stage's
-//                 partial sums (initial residual, complementarity), exactly the arithmetic of k_qp_setup
-//   W  write-out  the Jacobian part of the image as whole 16-byte pieces from LDS; everything else straight from the owner lanes
-// Registers: the composites (52 doubles) + one joint's vectors: ~190 VGPRs, no scratch; LDS 2.3 KB per node.
+//   S  set-up     every row stays with the lane that computed its coefficients (torque row g and collision rows g, g + 8 on lane g,
+//                 the network's row on lane 7, box rows i on lane i mod 8): bounds, initial slacks and multipliers, the stage's
+//                 partial sums (initial residual, complementarity) -- the arithmetic of k_qp_setup; C^T e of the stationarity
+//                 residual is a DPP butterfly sum over the 8 lanes
+//   W  write-out  straight from the owner lanes' registers: the Jacobian is never staged in LDS (it was, as the image's 156 doubles:
+//                 the block's 19 KB of LDS then needed a CU with at most six QP wavefronts; +8 KB of padding cost 3 % of a step)
+// Registers: composites (28 doubles) + this lane's rows (18 + 6 per collision row): < 256 VGPRs, no scratch; LDS 1.2 KB per node.
 //
 // The network's row (value and gradient w.r.t. the state, kernels_mlp.hpp) is evaluated BEFORE this pass and read from a compact
 // per-node buffer nn[node][1 + NX].
@@ -32,28 +35,23 @@
 namespace smpc {
 
 constexpr int SB_G = 8;   // lanes per node
-#ifndef SB_SKIP
-#define SB_SKIP 0       // timing experiments only (results are garbage): bit 0 collision rows, 1 pair loop, 2 scan, 3 set-up rows, 4 B columns
-#endif
 #ifndef SB_WAVES
 #define SB_WAVES 2      // wavefronts per SIMD the builder is compiled for (register cap 512 / SB_WAVES)
 #endif
 
-// per-node LDS block (offsets in doubles).  [Jacobian part of the stage image | exchange area, reused by the phases | small]
+// per-node LDS block (offsets in doubles): ONE exchange area, reused by the phases
 template <int NQ, int MR_MAX> struct SbLds {
-    static constexpr int NX = 2 * NQ, NZ = 3 * NQ, NQP = qp_even_c(NQ), MRP_MAX = qp_even_c(MR_MAX);
-    static constexpr int O_J = 0, NJ_MAX = NZ * NQP + NQ * MRP_MAX + NX;
-    static constexpr int O_X = O_J + NJ_MAX;
-    // phase G: sin / cos per joint | world points | (z, p, J_ee) per joint
-    static constexpr int X_SC = 0, X_PT = X_SC + 2 * NQ, X_ZP = X_PT + 3 * SMPC_MAX_POINTS, XG_END = X_ZP + 9 * NQ;
-    // phase R: (S, psi, chi) per joint
-    static constexpr int X_SPC = 0, XR_END = 18 * NQ;
-    // phase S: e = -(lambda_l - lambda_u) per row | z0 (the fixed dx_0 at node 0) | cost gradient w.r.t. q
-    static constexpr int X_E = 0, X_Z0 = 32, X_GQ = X_Z0 + NX, XS_END = X_GQ + NQ;
-    static constexpr int X_SIZE = XG_END > XR_END ? (XG_END > XS_END ? XG_END : XS_END) : (XR_END > XS_END ? XR_END : XS_END);
-    static constexpr int O_RV = O_X + X_SIZE;            // collision row values
-    static constexpr int O_TAU = O_RV + MR_MAX;          // torques
-    static constexpr int SIZE = qp_even_c(O_TAU + NQ);
+    static constexpr int NX = 2 * NQ;
+    // start: sin / cos per joint
+    static constexpr int X_SC = 0, XA_END = 2 * NQ;
+    // phase R: per joint (S | psi, then c_kk | chi, then d_kk | Yc_k S_k)
+    static constexpr int X_SPC = 0, SPC_D = 24, XR_END = SPC_D * NQ;
+    // phase G: world points | (z, p, J_ee) per joint
+    static constexpr int X_PT = 0, X_ZP = X_PT + 3 * SMPC_MAX_POINTS, XG_END = X_ZP + 9 * NQ;
+    // phase S: e = -(lambda_l - lambda_u) of the box rows | z0 (the fixed dx_0 at node 0) | cost gradient w.r.t. q
+    static constexpr int X_E = 0, X_Z0 = NX, X_GQ = X_Z0 + NX, XS_END = X_GQ + NQ;
+    static constexpr int m1 = XA_END > XR_END ? XA_END : XR_END, m2 = XG_END > XS_END ? XG_END : XS_END;
+    static constexpr int SIZE = qp_even_c(m1 > m2 ? m1 : m2);
 };
 
 // value of the lane OFF places up (lane i <- lane i + OFF) within its row of 16 lanes, as a DPP move: a VALU instruction with no
@@ -67,16 +65,23 @@ template <int OFF> __device__ __forceinline__ double dpp_up(double x) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double grp_sum(double v) {      // over the 8 lanes of a node
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
+// butterfly over the 8 lanes of a node, all as DPP moves: xor 1, xor 2 (quad permutes), then the mirror of the half row (i <-> 7 - i)
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double grp_sum(double v) {      // every lane of the group ends with the sum
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
     return v;
 }
 __device__ __forceinline__ double grp_max(double v) {
-    v = fmax(v, __shfl_xor(v, 1));
-    v = fmax(v, __shfl_xor(v, 2));
-    v = fmax(v, __shfl_xor(v, 4));
+    v = fmax(v, dpp_mov<0xB1>(v));
+    v = fmax(v, dpp_mov<0x4E>(v));
+    v = fmax(v, dpp_mov<0x141>(v));
     return v;
 }
 
@@ -90,19 +95,15 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
                                             const double* __restrict__ zl_st, const double* __restrict__ nnk, double* __restrict__ w) {
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NQP = QpLayout<NQ>::NQP, NZP = QpLayout<NQ>::NZP;
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS;
+    constexpr int NSLOT = (MR_MAX + SB_G - 1) / SB_G;      // collision rows per lane (row g + 8 s on lane g)
+    constexpr int NNL = SB_G - 1;                          // the lane that owns the network's row
     using LD = SbLds<NQ, MR_MAX>;
-    const int MR = Ly.MR, MRP = Ly.MRP, NRT = Ly.NRT;
+    const int MR = Ly.MR, MRP = Ly.MRP;
     const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;
     const bool last = (k == N);
     const bool jl = g < NQ;                       // this lane owns a joint
     const int gj = jl ? g : NQ - 1;               // (clamped: the other lanes shadow the last joint and write nothing)
-    double* const sJ = L + LD::O_J;               // image layout: Tt[c * NQP + r] | Gt[ix * MRP + r] | gn[i]
-    double* const sTT = sJ;
-    double* const sGT = sJ + NZ * NQP;
-    double* const sGN = sGT + NQ * MRP;
-    double* const sX = L + LD::O_X;
-    double* const sRV = L + LD::O_RV;
-    double* const sTau = L + LD::O_TAU;
+    double* const sX = L;
     const double dt = D->dt, cB = 0.5 * dt * dt;
 
     // ---- inputs: every lane of the group reads the node's state and control (same addresses: one transaction per group) -----------
@@ -112,8 +113,6 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
         qd[i] = xk[NQ + i];
         qdd[i] = last ? 0.0 : uk[i];
     }
-    // zero the Jacobian image (pads, the end node's torque block, rows that are off)
-    for (int e = g; e < LD::NJ_MAX; e += SB_G) sJ[e] = 0.0;
     {
         double s, c;
         sincos(xk[gj], &s, &c);
@@ -121,7 +120,7 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
     }
     lds_fence();
 
-    // ---- G: forward kinematics up to this lane's joint (world frame, as rnea_deriv.hpp / device_model.hpp) ------------------------
+    // ---- forward kinematics up to this lane's joint (world frame, as rnea_deriv.hpp / device_model.hpp) ---------------------------
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     rd::V3 pj = rd::v3(0, 0, 0);
     rd::SV S{rd::v3(0, 0, 0), rd::v3(0, 0, 0)}, vv{rd::v3(0, 0, 0), rd::v3(0, 0, 0)},
@@ -153,9 +152,9 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
         }
     }
     const rd::V3 zj = S.a;
+    lds_fence();     // (sin / cos have been read: the exchange area goes to the dynamics)
 
     // ---- R: torque row and its Jacobians (rnea_deriv.hpp, distributed) -------------------------------------------------------------
-    // own body: inertia about the world origin, h = Y v, f = Y a + v x* h, B column by column
     // The momentum operator of rnea_deriv.hpp, B m = Y (m x v) + m x* (Y v) + v x* (Y m), has a closed form with TWELVE numbers
     // instead of 36: with v = (w; u), h = Y v = (n; f) (f = m u + w x mc, the linear momentum) and m = (a; l),
     //     B m = (Baa a ; -2 f x a),   Baa = [w]x I - I [w]x - [n]x - (u mc^T + mc u^T - 2 (mc . u) 1)
@@ -202,13 +201,11 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
                 for (int cix = 0; cix < 3; cix++) {
                     double sacc = -Nx[3 * r + cix] - (uu[r] * mm3[cix] + mm3[r] * uu[cix]) + (r == cix ? mcu2 : 0.0);
 #pragma unroll
-                    for (int t = 0; t < 3; t++)
-                        if (t != r && t != cix) sacc += W[3 * r + t] * Im[3 * t + cix] - Im[3 * r + t] * W[3 * t + cix];
-                        else {
-                            if (t != r) sacc += W[3 * r + t] * Im[3 * t + cix];       // (the diagonal of [w]x is zero)
-                            if (t != cix) sacc -= Im[3 * r + t] * W[3 * t + cix];
-                        }
-                    Ba[3 * r + cix] = (SB_SKIP & 16) ? 0.0 : sacc;
+                    for (int t = 0; t < 3; t++) {
+                        if (t != r) sacc += W[3 * r + t] * Im[3 * t + cix];       // (the diagonal of [w]x is zero)
+                        if (t != cix) sacc -= Im[3 * r + t] * W[3 * t + cix];
+                    }
+                    Ba[3 * r + cix] = sacc;
                 }
         }
         // (lanes without a joint carry a zero body: mass 0, inertia 0 -> Y, B, f all zero)
@@ -216,7 +213,7 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
         const rd::SV psi = rd::mxm(vv, S);
         const rd::SV chi = rd::mxm(aa, S) - rd::mxm(psi, vv);
         if (jl) {
-            double* o = sX + LD::X_SPC + 18 * g;
+            double* o = sX + LD::X_SPC + LD::SPC_D * g;
             o[0] = S.a.x; o[1] = S.a.y; o[2] = S.a.z; o[3] = S.l.x; o[4] = S.l.y; o[5] = S.l.z;
             o[6] = psi.a.x; o[7] = psi.a.y; o[8] = psi.a.z; o[9] = psi.l.x; o[10] = psi.l.y; o[11] = psi.l.z;
             o[12] = chi.a.x; o[13] = chi.a.y; o[14] = chi.a.z; o[15] = chi.l.x; o[16] = chi.l.y; o[17] = chi.l.z;
@@ -235,12 +232,15 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
         acc(Pl.x); acc(Pl.y); acc(Pl.z);
         acc(F.a.x); acc(F.a.y); acc(F.a.z); acc(F.l.x); acc(F.l.y); acc(F.l.z);
     };
-    if (!(SB_SKIP & 4)) {
-        scan_step(std::integral_constant<int, 1>{});
-        scan_step(std::integral_constant<int, 2>{});
-        scan_step(std::integral_constant<int, 4>{});
-    }
+    scan_step(std::integral_constant<int, 1>{});
+    scan_step(std::integral_constant<int, 2>{});
+    scan_step(std::integral_constant<int, 4>{});
     lds_fence();
+    // this lane's torque row, in its registers: rowT[c] = d tau_g / d z_c, z = [u | q | v]
+    double rowT[NZ];
+#pragma unroll
+    for (int c = 0; c < NZ; c++) rowT[c] = 0.0;
+    double tau_g = 0.0;
     if (!last) {
         auto applyB = [&](const rd::SV& mv) {      // (Baa a ; -2 Pl x a)
             const rd::V3 a = mv.a;
@@ -249,42 +249,45 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
             return rd::SV{ya, rd::cross(Pl, a) * (-2.0)};
         };
         auto ld_sv = [&](const double* o) { return rd::SV{rd::v3(o[0], o[1], o[2]), rd::v3(o[3], o[4], o[5])}; };
-        // Pass 1, k = 0 .. NQ-1: every lane m >= k takes the pair (m, k): M[m][k] (= M[k][m]) and, for k < m, row m's entries
-        // dtau_m/dq_k, dtau_m/dqd_k.  The lane on the diagonal (m = k) keeps its own entries and leaves the two vectors the
-        // entries ABOVE the diagonal need, c_kk and d_kk + S_k x* F_k, in the LDS cells of psi_k / chi_k (dead after this pass).
-        // Pass 2, k = 1 .. NQ-1: every lane j < k: dtau_j/dqd_k = S_j . c_kk, dtau_j/dq_k = S_j . d_kk.  Tt[c][r], c: u | q | v.
+        auto st_sv = [&](double* o, const rd::SV& x) { o[0] = x.a.x; o[1] = x.a.y; o[2] = x.a.z; o[3] = x.l.x; o[4] = x.l.y; o[5] = x.l.z; };
+        // Pass 1, k = 0 .. NQ-1: every lane m >= k takes the pair (m, k): M[m][k] and row m's dtau_m/dq_k, dtau_m/dqd_k.  The lane on
+        // the diagonal (m = k) leaves the three vectors the entries ABOVE the diagonal need -- c_kk, d_kk + S_k x* F_k, Yc_k S_k --
+        // in LDS (over psi_k / chi_k, dead after this pass).  Pass 2, k = 1 .. NQ-1: every lane j < k: M[j][k] = S_j . Yc_k S_k,
+        // dtau_j/dqd_k = S_j . c_kk, dtau_j/dq_k = S_j . d_kk.
+        // (rolled loops: the row's entries are placed by select chains -- a register array cannot be indexed by the loop counter --
+        //  which costs 36 selects per pass but keeps the code and the register pressure of ONE pair)
+        auto put3 = [&](int kk, bool take, double m_, double dq_, double dv_) {
+#pragma unroll
+            for (int c = 0; c < NQ; c++) {
+                const bool hit = take && c == kk;
+                rowT[c] = hit ? m_ : rowT[c];
+                rowT[NQ + c] = hit ? dq_ : rowT[NQ + c];
+                rowT[2 * NQ + c] = hit ? dv_ : rowT[2 * NQ + c];
+            }
+        };
 #pragma unroll 1
-        for (int kk = 0; kk < ((SB_SKIP & 2) ? 0 : NQ); kk++) {
-            double* o = sX + LD::X_SPC + 18 * kk;
+        for (int kk = 0; kk < NQ; kk++) {
+            double* o = sX + LD::X_SPC + LD::SPC_D * kk;
             const rd::SV Sk = ld_sv(o), psi = ld_sv(o + 6), chi = ld_sv(o + 12);
             const rd::SV yS = rd::apply(Yc, Sk);
             const rd::SV cv = applyB(Sk) + rd::apply(Yc, psi) * 2.0;
             rd::SV dd = applyB(psi) + rd::apply(Yc, chi);
             if (kk == g) dd = dd + rd::mxf(Sk, F);
-            const double mm = rd::mdotf(S, yS), e_dv = rd::mdotf(S, cv), e_dq = rd::mdotf(S, dd);
-            if (kk <= g && jl) {
-                sTT[kk * NQP + g] = mm;            // M[g][kk]
-                sTT[g * NQP + kk] = mm;            // M[kk][g]
-                sTT[(2 * NQ + kk) * NQP + g] = e_dv;     // dtau_g / dqd_kk
-                sTT[(NQ + kk) * NQP + g] = e_dq;         // dtau_g / dq_kk
-            }
-            if (kk == g) {
-                o[6] = cv.a.x; o[7] = cv.a.y; o[8] = cv.a.z; o[9] = cv.l.x; o[10] = cv.l.y; o[11] = cv.l.z;
-                o[12] = dd.a.x; o[13] = dd.a.y; o[14] = dd.a.z; o[15] = dd.l.x; o[16] = dd.l.y; o[17] = dd.l.z;
-            }
+            put3(kk, kk <= g, rd::mdotf(S, yS), rd::mdotf(S, dd), rd::mdotf(S, cv));     // M[g][kk], dtau_g/dq_kk, dtau_g/dqd_kk
+            if (kk == g) { st_sv(o + 6, cv); st_sv(o + 12, dd); st_sv(o + 18, yS); }
         }
         lds_fence();
 #pragma unroll 1
-        for (int kk = 1; kk < ((SB_SKIP & 2) ? 0 : NQ); kk++) {
-            const double* o = sX + LD::X_SPC + 18 * kk;
-            const rd::SV cv = ld_sv(o + 6), dd = ld_sv(o + 12);
-            const double e_dv = rd::mdotf(S, cv), e_dq = rd::mdotf(S, dd);
-            if (g < kk) {
-                sTT[(2 * NQ + kk) * NQP + g] = e_dv;     // dtau_g / dqd_kk
-                sTT[(NQ + kk) * NQP + g] = e_dq;         // dtau_g / dq_kk
-            }
+        for (int kk = 1; kk < NQ; kk++) {
+            const double* o = sX + LD::X_SPC + LD::SPC_D * kk;
+            const rd::SV cv = ld_sv(o + 6), dd = ld_sv(o + 12), yS = ld_sv(o + 18);
+            put3(kk, g < kk, rd::mdotf(S, yS), rd::mdotf(S, dd), rd::mdotf(S, cv));
         }
-        if (jl) sTau[g] = rd::mdotf(S, F);
+        tau_g = rd::mdotf(S, F);
+        if (!jl) {
+#pragma unroll
+            for (int c = 0; c < NZ; c++) rowT[c] = 0.0;
+        }
     }
     lds_fence();     // (the exchange area changes hands: dynamics -> geometry)
 
@@ -343,90 +346,95 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
         }
         if (NQ * NQ < qp_even_c(NQ * NQ) && g == SB_G - 1 && valid) stnt_su(0.0, w + Ly.oIMG + Ly.iHQQ + NQ * NQ);
     }
-    // Collision rows (env_model.py:263-316): ONE ROW PER LANE (row r on lane r mod 8), value forward, gradient in reverse mode:
-    // the row's adjoints w.r.t. its (up to four) moving points, then d row / d q_j = z_j . sum over the points riding on links
-    // >= j of (P - p_j) x Pbar.  The clamps pass a derivative exactly where the forward-mode duals of device_model.hpp do
-    // (CasADi's tie rules, utils.py:94-118): clamp01(t) for 0 <= t <= 1, the point-segment clamp likewise.
-#pragma unroll 1
-    for (int r = g; r < ((SB_SKIP & 1) ? 0 : MR); r += SB_G) {
-        const smpc_row& row = D->rows[r];
+    // Collision rows (env_model.py:263-316): row g + 8 s ON LANE g, value forward, gradient in reverse mode: the row's adjoints
+    // w.r.t. its (up to four) moving points, then d row / d q_j = z_j . sum over the points riding on links >= j of
+    // (P - p_j) x Pbar.  The clamps pass a derivative exactly where the forward-mode duals of device_model.hpp do (CasADi's tie
+    // rules, utils.py:94-118): clamp01(t) for 0 <= t <= 1, the point-segment clamp likewise.  The row stays in this lane's registers.
+    double growv[NSLOT > 0 ? NSLOT : 1], grow[NSLOT > 0 ? NSLOT : 1][NQ];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; sl++) {
+        const int r = g + SB_G * sl;
+        const bool have = r < MR;
+        const smpc_row& row = D->rows[have ? r : 0];
         const rd::V3 Z0v = rd::v3(0, 0, 0);
         rd::V3 PA = Z0v, PB = Z0v, PC = Z0v, PD = Z0v, gA = Z0v, gB = Z0v, gC = Z0v, gD = Z0v;
         int lA = -1, lB = -1, lC = -1, lD = -1;      // links of the moving points (-1: fixed / unused)
-        double val;
-        if (row.kind == SMPC_ROW_SEG_FIXEDSEG || row.kind == SMPC_ROW_SEG_SEG) {
-            PA = ld_pt(row.pa); PB = ld_pt(row.pb);
-            lA = D->points[row.pa].link; lB = D->points[row.pb].link;
-            if (row.kind == SMPC_ROW_SEG_SEG) {
-                PC = ld_pt(row.pc); PD = ld_pt(row.pd);
-                lC = D->points[row.pc].link; lD = D->points[row.pd].link;
+        double val = 0.0;
+        if (have) {
+            if (row.kind == SMPC_ROW_SEG_FIXEDSEG || row.kind == SMPC_ROW_SEG_SEG) {
+                PA = ld_pt(row.pa); PB = ld_pt(row.pb);
+                lA = D->points[row.pa].link; lB = D->points[row.pb].link;
+                if (row.kind == SMPC_ROW_SEG_SEG) {
+                    PC = ld_pt(row.pc); PD = ld_pt(row.pd);
+                    lC = D->points[row.pc].link; lD = D->points[row.pd].link;
+                } else {
+                    PC = rd::v3(row.C[0], row.C[1], row.C[2]); PD = rd::v3(row.D[0], row.D[1], row.D[2]);
+                }
+                // utils.py:94-113
+                const rd::V3 ab = PB - PA, cd = PD - PC, ac = PC - PA;
+                const double Rr = rd::dot(ab, cd), S1 = rd::dot(ab, ac), D1 = rd::dot(ab, ab), S2 = rd::dot(cd, ac), D2 = rd::dot(cd, cd);
+                const double num = S1 * D2 - S2 * Rr, den = D1 * D2 - (Rr * Rr + 1e-5);
+                const double t0 = num / den;
+                const bool p1 = t0 <= 1.0 && t0 >= 0.0;
+                const double t1 = t0 <= 1.0 ? (t0 >= 0.0 ? t0 : 0.0) : 1.0;
+                const double u0 = (t1 * Rr - S2) / D2;
+                const bool p2 = u0 <= 1.0 && u0 >= 0.0;
+                const double u1 = u0 <= 1.0 ? (u0 >= 0.0 ? u0 : 0.0) : 1.0;
+                const double t2 = (u1 * Rr + S1) / D1;
+                const bool p3 = t2 <= 1.0 && t2 >= 0.0;
+                const double t3 = t2 <= 1.0 ? (t2 >= 0.0 ? t2 : 0.0) : 1.0;
+                const rd::V3 wv = ab * t3 - cd * u1 - ac;
+                val = rd::dot(wv, wv);
+                // reverse sweep
+                const rd::V3 wb = wv * 2.0;
+                rd::V3 abb = wb * t3, cdb = wb * (-u1), acb = wb * (-1.0);
+                const double t3b = rd::dot(wb, ab);
+                double u1b = -rd::dot(wb, cd);
+                const double t2b = p3 ? t3b : 0.0;
+                double Rb = t2b * u1 / D1, S1b = t2b / D1, D1b = -t2b * t2 / D1;
+                u1b += t2b * Rr / D1;
+                const double u0b = p2 ? u1b : 0.0;
+                const double t1b = u0b * Rr / D2;
+                Rb += u0b * t1 / D2;
+                double S2b = -u0b / D2, D2b = -u0b * u0 / D2;
+                const double t0b = p1 ? t1b : 0.0;
+                const double numb = t0b / den, denb = -t0b * t0 / den;
+                S1b += numb * D2; D2b += numb * S1 + denb * D1; S2b += -numb * Rr; Rb += -numb * S2 - 2.0 * denb * Rr; D1b += denb * D2;
+                abb = abb + cd * Rb + ac * S1b + ab * (2.0 * D1b);
+                cdb = cdb + ab * Rb + ac * S2b + cd * (2.0 * D2b);
+                acb = acb + ab * S1b + cd * S2b;
+                gA = Z0v - abb - acb; gB = abb; gC = acb - cdb; gD = cdb;
+            } else if (row.kind == SMPC_ROW_SEG_POINT) {
+                PA = ld_pt(row.pa); PB = ld_pt(row.pb);
+                lA = D->points[row.pa].link; lB = D->points[row.pb].link;
+                const rd::V3 Pp = rd::v3(row.C[0], row.C[1], row.C[2]);
+                // utils.py:115-118 (fmin(fmax(., 0), 1))
+                const rd::V3 pa_ = Pp - PA, ba = PB - PA;
+                const double t0 = rd::dot(pa_, ba) / row.len2;
+                const bool ps = t0 >= 0.0 && t0 <= 1.0;
+                const double t = t0 >= 0.0 ? (t0 <= 1.0 ? t0 : 1.0) : 0.0;
+                const rd::V3 wv = Pp - (PA + ba * t);
+                val = rd::dot(wv, wv);
+                const rd::V3 wb = wv * 2.0;
+                const double tb = -rd::dot(wb, ba);
+                const double t0b = (ps ? tb : 0.0) / row.len2;
+                gA = wb * (t - 1.0) - (ba + pa_) * t0b;
+                gB = wb * (-t) + pa_ * t0b;
+            } else if (row.kind == SMPC_ROW_POINT_POINT) {
+                PA = ld_pt(row.pa);
+                lA = D->points[row.pa].link;
+                const rd::V3 wv = PA - rd::v3(row.C[0], row.C[1], row.C[2]);
+                val = rd::dot(wv, wv);
+                gA = wv * 2.0;
             } else {
-                PC = rd::v3(row.C[0], row.C[1], row.C[2]); PD = rd::v3(row.D[0], row.D[1], row.D[2]);
+                PA = ld_pt(row.pa);
+                lA = D->points[row.pa].link;
+                val = (row.axis == 0 ? PA.x : (row.axis == 1 ? PA.y : PA.z)) - row.offset;
+                gA = rd::v3(row.axis == 0, row.axis == 1, row.axis == 2);
             }
-            // utils.py:94-113
-            const rd::V3 ab = PB - PA, cd = PD - PC, ac = PC - PA;
-            const double Rr = rd::dot(ab, cd), S1 = rd::dot(ab, ac), D1 = rd::dot(ab, ab), S2 = rd::dot(cd, ac), D2 = rd::dot(cd, cd);
-            const double num = S1 * D2 - S2 * Rr, den = D1 * D2 - (Rr * Rr + 1e-5);
-            const double t0 = num / den;
-            const bool p1 = t0 <= 1.0 && t0 >= 0.0;
-            const double t1 = t0 <= 1.0 ? (t0 >= 0.0 ? t0 : 0.0) : 1.0;
-            const double u0 = (t1 * Rr - S2) / D2;
-            const bool p2 = u0 <= 1.0 && u0 >= 0.0;
-            const double u1 = u0 <= 1.0 ? (u0 >= 0.0 ? u0 : 0.0) : 1.0;
-            const double t2 = (u1 * Rr + S1) / D1;
-            const bool p3 = t2 <= 1.0 && t2 >= 0.0;
-            const double t3 = t2 <= 1.0 ? (t2 >= 0.0 ? t2 : 0.0) : 1.0;
-            const rd::V3 wv = ab * t3 - cd * u1 - ac;
-            val = rd::dot(wv, wv);
-            // reverse sweep
-            const rd::V3 wb = wv * 2.0;
-            rd::V3 abb = wb * t3, cdb = wb * (-u1), acb = wb * (-1.0);
-            const double t3b = rd::dot(wb, ab);
-            double u1b = -rd::dot(wb, cd);
-            const double t2b = p3 ? t3b : 0.0;
-            double Rb = t2b * u1 / D1, S1b = t2b / D1, D1b = -t2b * t2 / D1;
-            u1b += t2b * Rr / D1;
-            const double u0b = p2 ? u1b : 0.0;
-            const double t1b = u0b * Rr / D2;
-            Rb += u0b * t1 / D2;
-            double S2b = -u0b / D2, D2b = -u0b * u0 / D2;
-            const double t0b = p1 ? t1b : 0.0;
-            const double numb = t0b / den, denb = -t0b * t0 / den;
-            S1b += numb * D2; D2b += numb * S1 + denb * D1; S2b += -numb * Rr; Rb += -numb * S2 - 2.0 * denb * Rr; D1b += denb * D2;
-            abb = abb + cd * Rb + ac * S1b + ab * (2.0 * D1b);
-            cdb = cdb + ab * Rb + ac * S2b + cd * (2.0 * D2b);
-            acb = acb + ab * S1b + cd * S2b;
-            gA = Z0v - abb - acb; gB = abb; gC = acb - cdb; gD = cdb;
-        } else if (row.kind == SMPC_ROW_SEG_POINT) {
-            PA = ld_pt(row.pa); PB = ld_pt(row.pb);
-            lA = D->points[row.pa].link; lB = D->points[row.pb].link;
-            const rd::V3 Pp = rd::v3(row.C[0], row.C[1], row.C[2]);
-            // utils.py:115-118 (fmin(fmax(., 0), 1))
-            const rd::V3 pa_ = Pp - PA, ba = PB - PA;
-            const double t0 = rd::dot(pa_, ba) / row.len2;
-            const bool ps = t0 >= 0.0 && t0 <= 1.0;
-            const double t = t0 >= 0.0 ? (t0 <= 1.0 ? t0 : 1.0) : 0.0;
-            const rd::V3 wv = Pp - (PA + ba * t);
-            val = rd::dot(wv, wv);
-            const rd::V3 wb = wv * 2.0;
-            const double tb = -rd::dot(wb, ba);
-            const double t0b = (ps ? tb : 0.0) / row.len2;
-            gA = wb * (t - 1.0) - (ba + pa_) * t0b;
-            gB = wb * (-t) + pa_ * t0b;
-        } else if (row.kind == SMPC_ROW_POINT_POINT) {
-            PA = ld_pt(row.pa);
-            lA = D->points[row.pa].link;
-            const rd::V3 wv = PA - rd::v3(row.C[0], row.C[1], row.C[2]);
-            val = rd::dot(wv, wv);
-            gA = wv * 2.0;
-        } else {
-            PA = ld_pt(row.pa);
-            lA = D->points[row.pa].link;
-            val = (row.axis == 0 ? PA.x : (row.axis == 1 ? PA.y : PA.z)) - row.offset;
-            gA = rd::v3(row.axis == 0, row.axis == 1, row.axis == 2);
         }
-        sRV[r] = val;
-#pragma unroll 1
+        growv[sl] = val;
+#pragma unroll
         for (int j = 0; j < NQ; j++) {
             const double* zo = sX + LD::X_ZP + 9 * j;
             const rd::V3 zz = rd::v3(zo[0], zo[1], zo[2]), pp = rd::v3(zo[3], zo[4], zo[5]);
@@ -435,12 +443,12 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
             acc = acc + rd::cross(PB - pp, gB) * (j <= lB ? 1.0 : 0.0);
             acc = acc + rd::cross(PC - pp, gC) * (j <= lC ? 1.0 : 0.0);
             acc = acc + rd::cross(PD - pp, gD) * (j <= lD ? 1.0 : 0.0);
-            sGT[j * MRP + r] = rd::dot(zz, acc);
+            grow[sl][j] = have ? rd::dot(zz, acc) : 0.0;
         }
     }
     lds_fence();     // (the exchange area changes hands: geometry -> set-up)
 
-    // ---- S: the stage record (the arithmetic of k_qp_setup) ------------------------------------------------------------------------
+    // ---- S: the stage record (the arithmetic of k_qp_setup), every row on the lane that holds its coefficients --------------------
     bool nn_on = false;
     if (D->nn_mode != SMPC_NN_NONE && k >= 1 && (D->nn_mode == SMPC_NN_ALL || last)) nn_on = pk[4] > 0.0;
     double wsoft = nn_on ? (last ? D->nn_soft_e : D->nn_soft_run) : -1.0;
@@ -448,51 +456,35 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
         wsoft = zl_st[k];    // cost_set(k, 'zl', .) on a row the formulation made soft; zero weight = row absent (k_qp_setup)
         if (wsoft == 0.0) { nn_on = false; wsoft = -1.0; }
     }
-    double nn_val = 0.0;
-    if (nn_on) {
-        nn_val = nnk[0];
-        for (int i = g; i < NX; i += SB_G) sGN[i] = nnk[1 + i];
-    }
-    double* const sE = sX + LD::X_E;
+    double* const sE = sX + LD::X_E;          // e of the box rows (they add to C^T e one column each)
     double* const sZ0 = sX + LD::X_Z0;
     double* const sGQ = sX + LD::X_GQ;
     for (int i = g; i < NX; i += SB_G) sZ0[i] = k == 0 ? x0b[i] - xk[i] : 0.0;
     if (jl) sGQ[g] = gz_q;
     lds_fence();
-    // dynamics defect b and the cost gradient; lane g: components g, g + 8, ...
+    // dynamics defect b; lane g: components g, g + 8
     double bmax = 0.0;
+    auto defect = [&](int i) -> double {
+        if (last) return 0.0;
+        const double* xn = xk + NX;
+        const int ii = i < NQ ? i : i - NQ;
+        const double ukk = uk[ii];
+        return i < NQ ? xk[ii] + dt * xk[NQ + ii] + cB * ukk - xn[ii] : xk[NQ + ii] + dt * ukk - xn[NQ + ii];
+    };
     for (int i = g; i < NX; i += SB_G) {
-        double bb = 0.0;
-        if (!last) {
-            const double* xn = xk + NX;
-            const int ii = i < NQ ? i : i - NQ;
-            const double ukk = uk[ii];
-            bb = i < NQ ? xk[ii] + dt * xk[NQ + ii] + cB * ukk - xn[ii] : xk[NQ + ii] + dt * ukk - xn[NQ + ii];
-        }
+        const double bb = defect(i);
         bmax = fmax(bmax, fabs(bb));
         if (valid) stnt_su(bb, w + Ly.oIMG + Ly.iB + i);
     }
     bmax = grp_max(bmax);
     const double bflag = bmax > 0.0 ? 1.0 : 0.0;
-    for (int i = g; i < NX; i += SB_G) {      // (second pass: the pairs need wsoft, which every lane has, and b again)
-        double bb = 0.0;
-        if (!last) {
-            const double* xn = xk + NX;
-            const int ii = i < NQ ? i : i - NQ;
-            const double ukk = uk[ii];
-            bb = i < NQ ? xk[ii] + dt * xk[NQ + ii] + cB * ukk - xn[ii] : xk[NQ + ii] + dt * ukk - xn[NQ + ii];
-        }
-        if (valid) stnt_su(dbl2{bb, wsoft}, reinterpret_cast<dbl2*>(w + Ly.oAUX) + i);
-    }
-    // cost gradient: u part R u, q part from the EE point, v part 0
-    auto gz_of = [&](int hz) -> double {
-        if (!reach || hz >= NZ) return 0.0;
-        if (hz < NU) return last ? 0.0 : cs * 2.0 * D->R * uk[hz];
-        return 0.0;      // (q part: owned by the joint lanes, below; v part: zero)
-    };
+    for (int i = g; i < NX; i += SB_G)
+        if (valid) stnt_su(dbl2{defect(i), wsoft}, reinterpret_cast<dbl2*>(w + Ly.oAUX) + i);
+    // cost gradient: u part R u, q part from the EE point (owned by the joint lanes), v part 0
+    auto gz_u = [&](int c) -> double { return (reach && !last) ? cs * 2.0 * D->R * uk[c] : 0.0; };
     for (int hz = g; hz < NZP; hz += SB_G) {
         if (hz >= NU && hz < NU + NQ) continue;
-        if (valid) stnt_su(gz_of(hz), w + Ly.oIMG + Ly.iGZ + hz);
+        if (valid) stnt_su(hz < NU ? gz_u(hz) : 0.0, w + Ly.oIMG + Ly.iGZ + hz);
     }
     if (jl && valid) stnt_su(gz_q, w + Ly.oIMG + Ly.iGZ + NU + g);
     if (g < 4 && valid) {
@@ -502,46 +494,13 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
     }
     if (valid) stnt_su(0.0, w + Ly.oWC + g);
 
-    // rows: r = g, g + 8, g + 16, g + 24
     double r0_loc = 0.0, mu_acc = 0.0, inf0 = 0.0;
     int cnt = 0;
-    // coefficient of general row rg (0-based among the general rows) in column c of z = [u q v]
-    auto coef = [&](int rg, int c) -> double {
-        if (rg < NQ) return sTT[c * NQP + rg];
-        if (rg < NQ + MR) return (c >= NU && c < NU + NQ) ? sGT[(c - NU) * MRP + (rg - NQ)] : 0.0;
-        return c >= NU ? sGN[c - NU] : 0.0;
-    };
-#pragma unroll 1
-    for (int r = g; r < ((SB_SKIP & 8) ? 0 : 32); r += SB_G) {
-        double lo = -QP_ABSENT, hi = QP_ABSENT;
+    // initial slacks / multipliers of one row (k_qp_setup); returns e = -(lambda_l - lambda_u)
+    auto init_row = [&](bool present, int r, double lo, double hi, double cz, double cn, bool soft) -> double {
         double tl = 1.0, ll = 0.0, tu = 1.0, lu = 0.0;
-        if (r < NRT) {
-            if (r < rT0) {
-                const double l = lo_k[r], h = hi_k[r];
-                if (k >= 1 && fabs(l) < SMPC_INF) lo = l - xk[r];
-                if (k >= 1 && fabs(h) < SMPC_INF) hi = h - xk[r];
-            } else if (r < rC0) {
-                const double tm = D->joints[r - rT0].tau_max;
-                if (!last && tm < SMPC_INF) { lo = -tm - sTau[r - rT0]; hi = tm - sTau[r - rT0]; }
-            } else if (r < rNN) {
-                const smpc_row& row = D->rows[r - rC0];
-                if (k >= 1 && fabs(row.lb) < SMPC_INF) lo = row.lb - sRV[r - rC0];
-                if (k >= 1 && fabs(row.ub) < SMPC_INF) hi = row.ub - sRV[r - rC0];
-            } else {
-                if (nn_on) lo = 0.0 - nn_val;
-            }
-            double cz, cn = 1.0;
-            if (r < NX) cz = sZ0[r];
-            else {
-                cz = 0.0;
-                cn = 0.0;
-                for (int c = 0; c < NZ; c++) {
-                    const double cv = coef(r - NX, c);
-                    cz = fma(cv, c >= NU ? sZ0[c - NU] : 0.0, cz);
-                    cn = fmax(cn, fabs(cv));
-                }
-            }
-            const bool soft = (r == rNN) && wsoft >= 0.0;
+        if (present) {
+            // slack floor of the starting point: a hard row starts at least QP_THR_HARD |c|_inf inside its bound
             const double thr = soft ? QP_THR : QP_THR_HARD * (cn > 0.0 ? cn : 1.0);
             if (lo > -QP_ABSENT) {
                 const double s0 = soft ? QP_THR : 0.0;
@@ -552,7 +511,7 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
                 r0_loc = fmax(r0_loc, fabs(slack - tl));
                 cnt += soft ? 2 : 1;
                 mu_acc += ll * tl;
-                if (soft) { mu_acc += (wsoft - ll) * s0; tu = s0; }
+                if (soft) { mu_acc += (wsoft - ll) * s0; tu = s0; }   // the slack rides in the unused upper side
             }
             if (hi < QP_ABSENT) {
                 const double slack = hi - cz;
@@ -567,55 +526,126 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
                 stnt_su(dbl2{tl, tu}, reinterpret_cast<dbl2*>(w + Ly.oR1) + r);
                 stnt_su(dbl2{ll, lu}, reinterpret_cast<dbl2*>(w + Ly.oR2) + r);
             }
-            // collision rows at node 0 (controller.py:77-79): constants of the QP; a violated one = QP infeasible
-            if (k == 0 && D->rows_at_node0 && r >= rC0 && r < rNN) {
-                const smpc_row& row = D->rows[r - rC0];
-                double v = sRV[r - rC0];
-                for (int c = 0; c < NZ; c++) v = fma(coef(r - NX, c), c >= NU ? sZ0[c - NU] : 0.0, v);
-                if ((fabs(row.lb) < SMPC_INF && v < row.lb - D->qp_tol) || (fabs(row.ub) < SMPC_INF && v > row.ub + D->qp_tol)) inf0 = 1.0;
-            }
         }
-        sE[r] = -(ll - lu);
-        if (valid) {
-            stnt_su(0.0, w + Ly.oCZA + r);
-            stnt_su(0.0, w + Ly.oCZN + r);
+        return -(ll - lu);
+    };
+    // box rows i = g, g + 8
+    for (int i = g; i < NX; i += SB_G) {
+        double lo = -QP_ABSENT, hi = QP_ABSENT;
+        const double l = lo_k[i], h = hi_k[i];
+        if (k >= 1 && fabs(l) < SMPC_INF) lo = l - xk[i];
+        if (k >= 1 && fabs(h) < SMPC_INF) hi = h - xk[i];
+        sE[i] = init_row(true, i, lo, hi, sZ0[i], 1.0, false);
+    }
+    // torque row g
+    double eT = 0.0;
+    {
+        double lo = -QP_ABSENT, hi = QP_ABSENT, cz = 0.0, cn = 0.0;
+        const double tm = D->joints[gj].tau_max;
+        if (!last && tm < SMPC_INF) { lo = -tm - tau_g; hi = tm - tau_g; }
+#pragma unroll
+        for (int c = 0; c < NZ; c++) cn = fmax(cn, fabs(rowT[c]));
+        if (k == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) cz = fma(rowT[NU + i], sZ0[i], cz);
+        }
+        eT = init_row(jl, rT0 + gj, lo, hi, cz, cn, false);
+        if (!jl) eT = 0.0;
+    }
+    // collision rows g + 8 s
+    double eC[NSLOT > 0 ? NSLOT : 1];
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; sl++) {
+        const int r = g + SB_G * sl;
+        const bool have = r < MR;
+        const smpc_row& row = D->rows[have ? r : 0];
+        double lo = -QP_ABSENT, hi = QP_ABSENT, cz = 0.0, cn = 0.0;
+        if (k >= 1 && fabs(row.lb) < SMPC_INF) lo = row.lb - growv[sl];
+        if (k >= 1 && fabs(row.ub) < SMPC_INF) hi = row.ub - growv[sl];
+#pragma unroll
+        for (int j = 0; j < NQ; j++) cn = fmax(cn, fabs(grow[sl][j]));
+        if (k == 0) {
+#pragma unroll
+            for (int j = 0; j < NQ; j++) cz = fma(grow[sl][j], sZ0[j], cz);
+        }
+        eC[sl] = init_row(have, rC0 + r, lo, hi, cz, cn, false);
+        if (!have) eC[sl] = 0.0;
+        // collision rows at node 0 (controller.py:77-79): constants of the QP; a violated one = QP infeasible
+        if (have && k == 0 && D->rows_at_node0) {
+            const double v = growv[sl] + cz;
+            if ((fabs(row.lb) < SMPC_INF && v < row.lb - D->qp_tol) || (fabs(row.ub) < SMPC_INF && v > row.ub + D->qp_tol)) inf0 = 1.0;
         }
     }
+    // the network's row: lane NNL
+    double eN = 0.0;
+    {
+        const bool mine = g == NNL;
+        double lo = -QP_ABSENT, cn = 0.0;
+        if (nn_on && mine) {
+            lo = 0.0 - nnk[0];
+            for (int i = 0; i < NX; i++) cn = fmax(cn, fabs(nnk[1 + i]));
+        }
+        // (the row exists from node 1 on: dx_0 never enters it)
+        eN = init_row(mine, rNN, lo, QP_ABSENT, 0.0, cn, wsoft >= 0.0);
+        if (!mine) eN = 0.0;
+    }
+    for (int r = g; r < 32; r += SB_G)
+        if (valid) { stnt_su(0.0, w + Ly.oCZA + r); stnt_su(0.0, w + Ly.oCZN + r); }
     for (int hz = g; hz < NZ; hz += SB_G) {
         const double z0 = hz >= NU ? sZ0[hz - NU] : 0.0;
         if (valid) { stnt_su(z0, w + Ly.oZ + hz); stnt_su(z0, w + Ly.oZN + hz); }
     }
     lds_fence();
-    // stationarity residual at the initial point (pi = 0): g - C^T (ll - lu); dx_0 does not enter
-    for (int hz = g; hz < NZ; hz += SB_G) {
-        if (!(k == 0 && hz >= NU) && !(last && hz < NU)) {
-            double a = (hz >= NU && hz < NU + NQ) ? sGQ[hz - NU] : gz_of(hz);
-            for (int rg = 0; rg < Ly.NRC; rg++) a = fma(coef(rg, hz), sE[NX + rg], a);
-            if (hz >= NU) a += sE[hz - NU];
-            r0_loc = fmax(r0_loc, fabs(a));
+    // stationarity residual at the initial point (pi = 0): g + C^T e; dx_0 does not enter.  This lane's share of C^T e, summed
+    // over the group by a DPP butterfly; the box rows' e come in from LDS
+    {
+        double pc[NZ];
+#pragma unroll
+        for (int c = 0; c < NZ; c++) pc[c] = rowT[c] * eT;
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; sl++)
+#pragma unroll
+            for (int j = 0; j < NQ; j++) pc[NU + j] = fma(grow[sl][j], eC[sl], pc[NU + j]);
+        if (nn_on && g == NNL) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) pc[NU + i] = fma(nnk[1 + i], eN, pc[NU + i]);
+        }
+#pragma unroll
+        for (int c = 0; c < NZ; c++) {
+            const double sc = grp_sum(pc[c]);
+            const bool skip = (k == 0 && c >= NU) || (last && c < NU);
+            const double gz = c < NU ? gz_u(c) : (c < NU + NQ ? sGQ[c - NU] : 0.0);
+            const double a = gz + sc + (c >= NU ? sE[c - NU] : 0.0);
+            r0_loc = fmax(r0_loc, skip ? 0.0 : fabs(a));
         }
     }
     if (!last) {
         for (int i = g; i < NX; i += SB_G) {
             double ax = 0.0;
             if (k == 0) ax = i < NQ ? sZ0[i] + dt * sZ0[NQ + i] : sZ0[i];
-            const double* xn = xk + NX;
-            const int ii = i < NQ ? i : i - NQ;
-            const double ukk = uk[ii];
-            const double bb = i < NQ ? xk[ii] + dt * xk[NQ + ii] + cB * ukk - xn[ii] : xk[NQ + ii] + dt * ukk - xn[NQ + ii];
-            r0_loc = fmax(r0_loc, fabs(ax + bb));
+            r0_loc = fmax(r0_loc, fabs(ax + defect(i)));
         }
     }
     const double R0 = grp_max(r0_loc), musum = grp_sum(mu_acc), cntsum = grp_sum((double)cnt), infs = grp_max(inf0);
     if (g < 4 && valid) w[Ly.oPART + g] = g == 0 ? R0 : (g == 1 ? musum : (g == 2 ? cntsum : infs));
 
-    // ---- W: the Jacobian part of the image, whole 16-byte pieces ---------------------------------------------------------------
-    {
-        const dbl2* s2 = reinterpret_cast<const dbl2*>(sJ);
-        dbl2* d2 = reinterpret_cast<dbl2*>(w + Ly.oIMG);
-        const int n2 = Ly.nJ >> 1;
-        if (valid)
-            for (int p2 = g; p2 < n2; p2 += SB_G) stnt_su(s2[p2], d2 + p2);
+    // ---- W: the Jacobian part of the image, straight from the rows' owners: Tt[c][r] | Gt[ix][r] | gn[i] -----------------------------
+    if (valid) {
+        double* img = w + Ly.oIMG;
+        if (g < NQP) {
+#pragma unroll
+            for (int c = 0; c < NZ; c++) stnt_su(rowT[c], img + Ly.iTT + c * NQP + g);      // (lanes NQ.. hold zeros: the pad rows)
+        }
+#pragma unroll
+        for (int sl = 0; sl < NSLOT; sl++) {
+            const int r = g + SB_G * sl;
+            if (r < MRP) {
+#pragma unroll
+                for (int j = 0; j < NQ; j++) stnt_su(grow[sl][j], img + Ly.iGT + j * MRP + r);   // (zeros in the pad row)
+            }
+        }
+        if (g == NNL)
+            for (int i = 0; i < NX; i++) stnt_su(nn_on ? nnk[1 + i] : 0.0, img + Ly.iGN + i);
     }
     lds_fence();     // (the next node of this group reuses the block)
 }
