@@ -1332,3 +1332,32 @@ def test_entry_scripts_end_to_end(tmp_path, monkeypatch):
     assert rc == len(res['collisions_idx'])
     parts = set(res['conv_idx']) | set(res['collisions_idx']) | set(res['unconv_idx']) | set(res['viable_idx'])
     assert parts == set(range(n))
+
+
+@pytest.mark.parametrize('on_device', [True, False])
+def test_run_mpc_reports_the_reference_solver_time_statistics(on_device, capsys):
+    """scripts/mpc.py:239 appends controller.getTime() at every step and :300-303 prints the 99 % quantile of
+    the seven acados timers.  run_mpc(collect_times=True) on the engine: one row per step and group -- on the device the rows
+    come out of the engine's 64-deep event ring, read at least 32 solves late (70 steps: the ring is lapped once) -- with
+    time_tot >= time_qp >= time_qp_solver_call > 0, time_lin > 0, and nothing else changed by collecting them."""
+    from safe_mpc_amd import closed_loop as cl
+    from safe_mpc_amd.parser import Parameters
+    par = Parameters({}, 'z1')
+    par.nq, par.n_dof_safe_set, par.net_size, par.N, par.back_hor = 6, 6, [12, 256, 1], 10, 10
+    probe = make_problem('st', 'ext', N=10)[1]
+    B, n_steps = 40, 70
+    x0 = sample_instances(probe, B, seed=1)
+    xg, ug = np.repeat(x0[:, None, :], 11, axis=1), np.zeros((B, 10, 6))
+    res = cl.run_mpc(par, 'st', xg, ug, n_steps=n_steps, on_device=on_device, collect_times=True, groups=2 if on_device else 1)
+    ts = res['time_stats']
+    groups = 2 if on_device else 1
+    assert res['time_fields'] == ['time_lin', 'time_sim', 'time_qp', 'time_qp_solver_call', 'time_glob', 'time_reg', 'time_tot']
+    assert ts.shape == (groups * n_steps, 7) and res['time_lost'] == 0
+    lin, sim, qp, call, glob, reg, tot = ts.T
+    assert np.all(tot > 0) and np.all(lin > 0) and np.all(call > 0)
+    assert np.all(tot >= qp - 1e-9) and np.all(qp >= call - 1e-9)
+    assert np.all(sim == 0) and np.all(glob == 0) and np.all(reg == 0)
+    assert np.all(tot < 0.5)                                          # seconds, like acados' get_stats
+    assert np.allclose(res['time_q99'], np.quantile(ts, 0.99, axis=0))
+    ref = cl.run_mpc(par, 'st', xg, ug, n_steps=n_steps, on_device=on_device, groups=groups)
+    assert 'time_stats' not in ref and np.array_equal(np.nan_to_num(ref['x']), np.nan_to_num(res['x']))
