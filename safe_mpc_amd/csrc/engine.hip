@@ -348,6 +348,14 @@ static size_t qp_pad_lds() {
     return v;
 }
 
+// k_qp_ipm's non-temporal variant: -1 (default) by workspace size, 0 / 1 forced (SMPC_QP_NT, A/B runs).  The threshold sits between
+// what was measured to lose (a 244 MB sub-batch workspace, three of them in flight) and to win (489 MB, three in flight).
+constexpr size_t qp_nt_threshold = (size_t)384 << 20;
+static int qp_nt_mode() {
+    static const int v = [] { const char* e = getenv("SMPC_QP_NT"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
 // 1: the lane-cooperative stage builder (kernel_build.hpp: MLP -> k_stage_build -> k_qp_ipm), the default; 0: the thread-per-node
 // kernels of rounds 1-3 (k_node_linearise -> MLP -> k_qp_setup -> k_qp_ipm), kept for A/B runs and as what smpc_eval_nodes uses
 static int stage_build_mode() {
@@ -445,13 +453,15 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         HIPCHK(h, hipMemcpyAsync(h->d_wstat, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
         wstat = h->d_wstat;
     }
-#define SMPC_QP_LAUNCH(MR_)                                                                                                        \
-    hipLaunchKernelGGL((k_qp_ipm<NQ, MR_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,       \
+    // non-temporal workspace accesses once this launch's workspace is well beyond the Infinity Cache (kernel_qp.hpp, k_qp_ipm)
+    const bool nt = qp_nt_mode() < 0 ? ws_doubles_per_instance(h->desc, h->N) * sizeof(double) * (size_t)B >= qp_nt_threshold : qp_nt_mode() > 0;
+#define SMPC_QP_LAUNCH(MR_, NT_)                                                                                                   \
+    hipLaunchKernelGGL((k_qp_ipm<NQ, MR_, NT_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,  \
                        ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active)
     switch (h->desc.n_rows) {
-    case 6: SMPC_QP_LAUNCH(6); break;
-    case 4: SMPC_QP_LAUNCH(4); break;
-    default: SMPC_QP_LAUNCH(-1); break;
+    case 6: if (nt) SMPC_QP_LAUNCH(6, true); else SMPC_QP_LAUNCH(6, false); break;
+    case 4: if (nt) SMPC_QP_LAUNCH(4, true); else SMPC_QP_LAUNCH(4, false); break;
+    default: SMPC_QP_LAUNCH(-1, false); break;      // (the runtime-row-count instantiation is not built twice)
     }
 #undef SMPC_QP_LAUNCH
     h->order_B = B;

@@ -576,7 +576,14 @@ __global__ __launch_bounds__(32 * EV_TILE) void k_qp_setup(const smpc_problem_de
 // =========================================================================================================================
 // k_qp_ipm
 // =========================================================================================================================
-template <int NQ, int MRT>
+// NT: the wide accesses of the stage workspace -- 16-byte loads of every sweep, the factorisation sweep's wide stores -- are
+// non-temporal.  The workspace is a stream (every block is touched once per sweep by one wavefront and comes round again long after
+// its XCD's 4 MB L2 has turned over), so for a workspace far larger than the 256 MB Infinity Cache `nt` is a plain win: C1's loop at
+// 8192 / 16384 / 32768 / 65536 instances -5 / -12 / -14 / -16 % per step (round 4, A/B in one session).  At the headline 4096 (three
+// sub-batch workspaces of 244 MB) it LOSES 2-3 %: part of a sub-batch's workspace survives in the Infinity Cache between a
+// stage builder and the first sweeps, and between sweeps, and nt gives that up.  The engine picks by the handle's workspace size
+// (engine.hip: qp_nt_threshold); results do not depend on it.
+template <int NQ, int MRT, bool NT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER_EU, QP_WAVES_PER_EU))) void k_qp_ipm(
     const smpc_problem_desc* __restrict__ D, int B, int N, const double* __restrict__ x0, const double* __restrict__ xg,
     const double* __restrict__ ug, double* __restrict__ ws_all, double* __restrict__ x_out, double* __restrict__ u_out,
@@ -585,6 +592,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
                   LC0 = LyT::LC0, KS = LyT::KS, NWP = LyT::NWP;
+    // (the wide workspace accesses of this kernel: these two shadow the build-time-selectable helpers of the same names)
+    auto ldnt = [](auto* p) {
+        if constexpr (NT || (SMPC_NT_MASK & 1)) return __builtin_nontemporal_load(p);
+        else return *p;
+    };
+    auto stnt_b1 = [](auto v, auto* p) {
+        if constexpr (NT || (SMPC_NT_MASK & 2)) __builtin_nontemporal_store(v, p);
+        else *p = v;
+    };
     // load-balance probe (smpc_get_qp_wave_stats): two reads of the constant 100 MHz clock per half-wave; the first one is
     // parked in LDS (the kernel has no register to spare)
     __shared__ unsigned long long s_tbegin[2];
