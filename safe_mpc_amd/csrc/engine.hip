@@ -261,36 +261,41 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
     }
     hipLaunchKernelGGL((k_nn_features<NQ>), dim3((Mp + 63) / 64), dim3(64), 0, s, h->d_desc, M, Mp, N, mode, d_x,
                        h->d_S, idx, live);
-    const dim3 blk(256), grd(Mp / 128, H / 64);
+    // The layer-by-layer GEMMs.  Default (round 4): k_gemm_f32 as ONE-WAVE blocks -- a wavefront of it is self-contained (32 x 64
+    // tile, operands from L2, 90-130 registers, no LDS), so its blocks start on any SIMD with one free slot.  The 128 x 128
+    // LDS-tiled kernel (256-thread blocks: 200 registers per lane on all four SIMDs of one CU at once + 37 KB of LDS) is 12 % faster
+    // alone on the GPU (90 vs 79 TFLOP/s) but in C4's loop its blocks wait for CUs that QP wavefronts keep refilling: 12-14 ms per
+    // solve for 1.9 ms of work (profiles/r04_c4_kernel_summary_by_grid.txt).  SMPC_MLP_GEMM=tiled brings it back (A/B runs); the
+    // choice then follows the rows of the whole call as before (the two kernels sum K in different orders).
+    static const bool use_tiled_env = [] { const char* e = getenv("SMPC_MLP_GEMM"); return e && !strcmp(e, "tiled"); }();
+    const long rows_sel = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128 : (long)Mp;
+    const bool tiled = use_tiled_env && rows_sel >= 8192 && H % 128 == 0;
+    const dim3 blk(tiled ? 256 : 64), blk_t(256);
+    const dim3 grd(tiled ? Mp / 128 : Mp / 32, H / 64), grd_t(Mp / 128, H / 128);
     hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, MLP_KPAD, h->d_S, h->d_Wfwd[0], h->d_bias[0],
                        (const float*)nullptr, h->d_act[0], h->d_dg[0], live, h->act);
-    // hidden x hidden layers: LDS-tiled kernel once there are enough 128 x 128 tiles to fill the chip.  The two kernels sum K
-    // in different orders, so a sub-batch worker decides by the rows of the whole call (results do not depend on the split).
-    const long rows_sel = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128 : (long)Mp;
-    const bool tiled = rows_sel >= 8192 && H % 128 == 0;
-    const dim3 grd_t(Mp / 128, H / 128);
     for (int l = 1; l + 1 < L; l++) {
         if (tiled)
-            hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_BIAS_GELU>), grd_t, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
+            hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_BIAS_GELU>), grd_t, blk_t, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
                                h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live, h->act);
         else
             hipLaunchKernelGGL((k_gemm_f32<EPI_BIAS_GELU>), grd, blk, 0, s, Mp, H, H, h->d_act[l - 1], h->d_Wfwd[l],
                                h->d_bias[l], (const float*)nullptr, h->d_act[l], h->d_dg[l], live, h->act);
     }
-    hipLaunchKernelGGL(k_nn_output, dim3((Mp + 3) / 4), blk, 0, s, Mp, H, h->d_act[L - 2], h->d_dg[L - 2],
+    hipLaunchKernelGGL(k_nn_output, dim3((Mp + 3) / 4), dim3(256), 0, s, Mp, H, h->d_act[L - 2], h->d_dg[L - 2],
                        h->d_Wbwd[L - 1], h->d_bias[L - 1], h->d_y, h->d_dA, live);
     if (backward) {
         float *cur = h->d_dA, *nxt = h->d_dB;
         for (int l = L - 2; l >= 1; l--) {
             if (tiled)
-                hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_MUL>), grd_t, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l],
+                hipLaunchKernelGGL((k_gemm_f32_tiled<EPI_MUL>), grd_t, blk_t, 0, s, Mp, H, H, cur, h->d_Wbwd[l],
                                    (const float*)nullptr, h->d_dg[l - 1], nxt, (float*)nullptr, live, h->act);
             else
                 hipLaunchKernelGGL((k_gemm_f32<EPI_MUL>), grd, blk, 0, s, Mp, H, H, cur, h->d_Wbwd[l], (const float*)nullptr,
                                    h->d_dg[l - 1], nxt, (float*)nullptr, live, h->act);
             float* t = cur; cur = nxt; nxt = t;
         }
-        hipLaunchKernelGGL((k_gemm_f32<EPI_PLAIN>), dim3(Mp / 128, MLP_NPAD / 64), blk, 0, s, Mp, MLP_NPAD, H, cur,
+        hipLaunchKernelGGL((k_gemm_f32<EPI_PLAIN>), dim3(tiled ? Mp / 128 : Mp / 32, MLP_NPAD / 64), blk, 0, s, Mp, MLP_NPAD, H, cur,
                            h->d_Wbwd[0], (const float*)nullptr, (const float*)nullptr, h->d_GS, (float*)nullptr, live, h->act);
     }
     HIPCHK(h, hipGetLastError());

@@ -53,8 +53,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const flo
                                                   const float* __restrict__ Bm, const float* __restrict__ bias,
                                                   const float* __restrict__ aux, float* __restrict__ out1,
                                                   float* __restrict__ out2, const int32_t* __restrict__ m_live, int act) {
+    // (the wavefronts of a block are independent -- no LDS, no barrier -- so the block size is the launch's choice: 256 threads, or
+    //  64 where the kernel has to find room beside resident QP wavefronts, engine.hip run_mlp)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    const int m0 = (blockIdx.x * (int)(blockDim.x >> 6) + wave) * 32;
     const int n0 = blockIdx.y * 64;
     if (m0 >= M) return;
     if (m_live && m0 >= *m_live) return;   // (rows past the live count of a compacted list: nothing to compute)
