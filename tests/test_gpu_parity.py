@@ -489,8 +489,24 @@ def test_eval_nodes_device_path_matches_host_path():
         assert np.array_equal(np.asarray(a[f]), b[f].cpu().numpy()), f
 
 
-def test_mlp_tiled_gemm_path():
-    """The safe-set row on every node of 512 instances x 16 stages = 8 192 MLP rows takes the LDS-tiled GEMM kernel."""
+def test_mlp_tiled_gemm_kernel_in_a_child_process():
+    """The 128 x 128 LDS-tiled GEMM kernel is no longer the default for large row counts (round 4: one-wave blocks of k_gemm_f32,
+    DESIGN section 4) but stays selectable with SMPC_MLP_GEMM=tiled for A/B runs; the knob is read once per process, so the
+    kernel is exercised in a child process running test_mlp_layer_by_layer_gemm_path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMPC_MLP_GEMM='tiled')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x', '-k',
+                        'test_mlp_layer_by_layer_gemm_path'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '1 passed' in r.stdout
+
+
+def test_mlp_layer_by_layer_gemm_path():
+    """The safe-set row on every node of 512 instances x 16 stages = 8 192 MLP rows: the layer-by-layer GEMM kernels (from that
+    row count on also the LDS-tiled one when SMPC_MLP_GEMM=tiled)."""
     par, prob, net = make_problem('constraint_everywhere', 'ext', N=16)
     s, o = _solver(prob, net), _oracle(prob, net)
     B = 512
