@@ -9,15 +9,17 @@
 // code) and only starts on SIMDs that hold no QP wavefront; k_qp_setup's blocks need 23 KB of LDS next to the QP wavefronts' 148 KB;
 // and the 2.6 KB linearisation record of every node makes a round trip through HBM between them.
 //
-// Mapping: SB_G = 8 lanes per node (a wavefront = 8 nodes), lane g < NQ owns joint g.
-//   G  geometry   lane g runs the forward kinematics up to ITS joint (sin / cos of every joint computed once, by its owner, and
-//                 shared through LDS), publishes its axis / origin and the world points riding on its link; then: its row of the EE
-//                 cost Hessian, its entry of the cost gradient, and -- with ONE tangent direction, its own joint -- every collision
-//                 row's value and d row / d q_g (forward mode, the clamps' tie rules of utils.py:94-118 as in device_model.hpp)
-//   R  dynamics   closed-form derivatives of rnea_deriv.hpp, distributed: lane g computes its body's spatial inertia Y_g, momentum
-//                 operator B_g and force f_g; a suffix scan over the lanes (wave shuffles) makes them the composites Yc_g, Bc_g, F_g;
-//                 lane m then walks k = 0..m with S_k, psi_k, chi_k of the other joints from LDS and fills row m (k < m) and
-//                 column m (j <= m) of M, dtau/dq, dtau/dqd -- written into the stage image's transposed Jacobian Tt[c][r] in LDS
+// Mapping: SB_G = 8 lanes per node (a wavefront = 8 nodes), lane g < NQ owns joint g.  In program order:
+//   K  kinematics lane g runs the forward kinematics up to ITS joint (sin / cos of every joint computed once, by its owner, and
+//                 shared through LDS): R_g, p_g, S_g, v_g, a_g in world coordinates
+//   R  dynamics   closed-form derivatives of rnea_deriv.hpp, distributed: lane g computes its body's spatial inertia Y_g, force f_g
+//                 and momentum operator B_g (12 numbers, below); a suffix scan over the lanes (DPP moves) makes them the composites
+//                 of bodies g..NQ-1; lane m then takes the pairs (m, k <= m) with S_k, psi_k, chi_k of the other joints from LDS,
+//                 and in a second pass the pairs (m, k > m) from the three vectors the diagonal lanes left there: row m of M,
+//                 dtau/dq, dtau/dqd ends up in lane m's registers
+//   G  geometry   axis / origin of every joint and the world points riding on each link published through LDS; lane g: its entry of
+//                 the cost gradient, its row of the (exact or Gauss-Newton) EE cost Hessian; collision rows g, g + 8: value
+//                 forward, gradient in reverse mode (the clamps' tie rules of utils.py:94-118 as in device_model.hpp)
 //   S  set-up     every row stays with the lane that computed its coefficients (torque row g and collision rows g, g + 8 on lane g,
 //                 the network's row on lane 7, box rows i on lane i mod 8): bounds, initial slacks and multipliers, the stage's
 //                 partial sums (initial residual, complementarity) -- the arithmetic of k_qp_setup; C^T e of the stationarity
@@ -55,8 +57,8 @@ template <int NQ, int MR_MAX> struct SbLds {
 };
 
 // value of the lane OFF places up (lane i <- lane i + OFF) within its row of 16 lanes, as a DPP move: a VALU instruction with no
-// round trip through the LDS crossbar (the composites' suffix scan moves 156 doubles this way; as ds_bpermute it was latency-bound:
-// 0.21 of the builder's 0.56 ms).  Lanes whose source lies outside the row read 0 (bound_ctrl).
+// round trip through the LDS crossbar (the composites' suffix scan moves 3 x 28 doubles this way; as ds_bpermute, and with the
+// 36-entry B, it was latency-bound: 0.21 of the first version's 0.56 ms).  Lanes whose source lies outside the row read 0 (bound_ctrl).
 template <int OFF> __device__ __forceinline__ double dpp_up(double x) {
     static_assert(OFF >= 1 && OFF <= 15, "row_shl:1..15");
     int lo = __double2loint(x), hi = __double2hiint(x);
