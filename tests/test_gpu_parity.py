@@ -387,6 +387,84 @@ def test_stage_builder_equals_thread_per_node_kernels(case):
     assert np.abs(old[:, :, oIMG:oIMG + nJ]).max() > 0
 
 
+@pytest.mark.parametrize('case', ['st', 'constraint_everywhere', 'zerovel_nls', 'fr7'])
+def test_stage_builder_records_equal_oracle_qp(case):
+    """The stage records the builder writes (the QP the interior point then solves) against the oracle's stage QP
+    (Oracle.build_qp: link-frame Newton-Euler with dual numbers, dense stage matrices -- nothing shared), entry by entry:
+    constraint Jacobian (torque rows' M | dtau/dq | dtau/dqd, collision rows, the network's row), cost Hessian and gradient,
+    dynamics defect, bounds.  1e-9 of each block's scale (the tolerance of test_eval_nodes_parity, which covers the
+    thread-per-node kernels behind smpc_eval_nodes); the network's row 2e-4 (fp32 MFMA against the oracle's fp64 restatement)."""
+    from conftest import make_problem_fr7
+    N = 10
+    if case == 'fr7':
+        par, prob, net = make_problem_fr7(N=N)
+    elif case == 'zerovel_nls':
+        par, prob, net = make_problem('zerovel', 'nls', N=N)
+    else:
+        par, prob, net = make_problem(case, 'ext', N=N)
+    nq, nx, nu = prob.nq, prob.nx, prob.nu
+    B = 5
+    s, o = _solver(prob, net), _oracle(prob, net)
+    x0 = sample_instances(prob, B, seed=4, vel_scale=0.3)
+    xg, ug, p = constant_guess(prob, x0, ee_ref=prob.ee_ref)
+    rng = np.random.default_rng(3)
+    ug += rng.uniform(-3, 3, ug.shape)
+    xg = s.guess_correction(xg, ug)
+    xg[:, 1:] += 0.01 * rng.standard_normal(xg[:, 1:].shape)
+    x0 = x0 + 0.003 * rng.standard_normal(x0.shape)
+    ws, lay = _stage_records(s, x0, xg, ug, p, 1)
+    stride, nIMG, oIMG, oSL, oAUX, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, per = [int(v) for v in lay[:15]]
+    ws = ws.reshape(B, N + 1, stride)
+    MR = prob.desc.n_rows
+    NQP, MRP, NZ = nq + nq % 2, MR + MR % 2, 3 * nq
+    iTT, iGT, iGN = 0, NZ * NQP, NZ * NQP + nq * MRP
+    iHQQ = iGN + nx
+    iGZ = iHQQ + nq * nq + (nq * nq) % 2
+    iB = iGZ + NZ + NZ % 2
+    assert iB + nx + 4 == nIMG and iHQQ == nJ
+
+    def close(a, b, tol, what):
+        scale = np.abs(b).max() + 1e-300
+        assert np.abs(a - b).max() <= tol * scale + 1e-12, (case, what, np.abs(a - b).max(), scale)
+    for b in range(B):
+        qp = o.build_qp(x0[b], xg[b], ug[b], p[b])
+        for k in range(N + 1):
+            img = ws[b, k, oIMG:oIMG + nIMG]
+            last = k == N
+            off = 0 if last else nu                        # the oracle's stage variable is [u; x], [x] at the end
+            Cm, H, g = qp['C'][k], qp['H'][k], qp['g'][k]
+            TT = img[iTT:iTT + NZ * NQP].reshape(NZ, NQP)[:, :nq]                      # Tt[c][r]
+            GT = img[iGT:iGT + nq * MRP].reshape(nq, MRP)[:, :MR] if MR else np.zeros((nq, 0))
+            GN = img[iGN:iGN + nx]
+            if not last:
+                close(TT.T, Cm[nx:nx + nq, :NZ], 1e-9, 'torque rows')
+            else:
+                assert np.all(TT == 0.0)
+            close(GT.T, Cm[nx + nq:nx + nq + MR, off:off + nq], 1e-9, 'collision rows')
+            close(GN, Cm[nx + nq + MR, off:off + nx], 2e-4, 'network row')
+            close(img[iHQQ:iHQQ + nq * nq].reshape(nq, nq), H[off:off + nq, off:off + nq], 1e-9, 'cost Hessian')
+            gz = img[iGZ:iGZ + NZ]
+            if not last:
+                close(gz[:nu], g[:nu], 1e-12, 'cost gradient u')
+            close(gz[nu:nu + nq], g[off:off + nq], 1e-9, 'cost gradient q')
+            assert np.all(gz[nu + nq:] == 0.0)
+            close(img[iB:iB + nx], qp['b'][k][:nx], 1e-9, 'defect')
+            if not last:
+                assert abs(img[iB + nx] - H[0, 0]) <= 1e-12 * abs(H[0, 0])          # Huu diagonal
+            r0 = ws[b, k, oR0:oR0 + 2 * NRT].reshape(NRT, 2)
+            nr = int(qp['nr'][k])
+            assert nr == NRT
+            lo = np.where(qp['has_lo'][k][:nr], qp['lo'][k][:nr], -1e300)
+            hi = np.where(qp['has_hi'][k][:nr], qp['hi'][k][:nr], 1e300)
+            absent = np.abs(r0) >= 1e299
+            assert np.array_equal(absent[:, 0], lo <= -1e299) and np.array_equal(absent[:, 1], hi >= 1e299), (case, b, k)
+            rows_fp64 = np.arange(nr) != nx + nq + MR               # (the network's row: its value is an fp32 product)
+            close(np.where(absent[:, 0], 0.0, r0[:, 0])[rows_fp64], np.where(absent[:, 0], 0.0, lo)[rows_fp64], 1e-9, 'lower bounds')
+            close(np.where(absent[:, 1], 0.0, r0[:, 1])[rows_fp64], np.where(absent[:, 1], 0.0, hi)[rows_fp64], 1e-9, 'upper bounds')
+            if not absent[nx + nq + MR, 0]:
+                assert abs(r0[nx + nq + MR, 0] - lo[nx + nq + MR]) < 2e-4 * (1 + abs(lo[nx + nq + MR]))
+
+
 @pytest.mark.parametrize('N', [1, 2, 3, 63])
 def test_horizon_extremes(N):
     """Shortest horizons (the unrolled / look-ahead loops of the QP kernel degenerate) and SMPC_MAX_N."""
