@@ -256,8 +256,9 @@ int smpc_plant_step(smpc_handle* h, int B, const double* x, const double* u, con
  * noise).  x_guess / u_guess are the warm start on entry and the shifted guess of the last step on return.
  * Trajectories are STEP-major: x_traj[n_steps+1][B][nx] (x_traj[0] = x0), u_traj[n_steps][B][nu], status_traj[n_steps][B],
  * iter_traj[n_steps][B] (may be NULL), tau_noise[n_steps][B][nq] or NULL, joints_noisy[B][nq] or NULL.
- * Large batches (B >= 1024) are split into two sub-batches that advance on their own streams inside the engine (worker
- * handles sharing the network weights): the long tail of one sub-batch's QP launch overlaps the bulk of the other's.  The
+ * Large batches are split into two (B >= 1024) or three (B >= 3072) sub-batches that advance on their own streams inside the
+ * engine (worker handles sharing the network weights): the long tail of one sub-batch's QP launch overlaps the bulk of the
+ * others'.  The
  * environment variable SMPC_ROLLOUT_STREAMS overrides the number of sub-batches; results do not depend on it. */
 int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, double* x_guess, double* u_guess,
                        const double* p, const smpc_joint* joints_noisy, const double* tau_noise, double* x_traj,

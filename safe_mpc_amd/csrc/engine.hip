@@ -1045,8 +1045,9 @@ int smpc_rollout_batch(smpc_handle* h, int B, int n_steps, const double* x0, dou
     }
     // ---- the steps.  Instances are independent, so a large batch is split into sub-batches that advance on their own
     // streams (worker handles): while one sub-batch's QP launch waits for its slowest instances the others' kernels fill the
-    // chip (scripts/rollout_bench.py, B = 4096, round 3: 4.12 / 3.77 / 3.67 / 3.64 ms per step with 1 / 2 / 3 / 4 sub-batches; the
-    // Python-driven three-stream loop of bench.py: 3.57 over the same 40 steps).  Results are the same bits whatever the split.
+    // chip (scripts/rollout_bench.py, B = 4096, round 4: 3.53 / 3.06 / 3.04 / 3.07 ms per step with 1 / 2 / 3 / 4 sub-batches,
+    // twice on one box; the Python-driven three-stream loop of bench.py: 2.9 over the same 40 steps).  Results are the same bits
+    // whatever the split.
     int n_sub = B >= 3072 ? 3 : (B >= 1024 ? 2 : 1);
     if (const char* ev = getenv("SMPC_ROLLOUT_STREAMS")) n_sub = atoi(ev);
     if (n_sub < 1) n_sub = 1;

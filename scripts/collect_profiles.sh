@@ -33,5 +33,6 @@ timeout -k 10 300 python3 bench.py --batch 65536 --noise 10 --control-noise 1 --
 SMPC_BENCH_CONTROLLER=constraint_everywhere timeout -k 10 300 python3 bench.py --no-cpu-baseline > $O/bench_constraint_everywhere.json 2>> $O/bench.err
 timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-survey-window > $O/bench_100steps.json 2>> $O/bench.err
 SMPC_STEPS=60 timeout -k 10 400 python3 scripts/policy_bench.py st htwa receding real_receding > $O/policy_bench.txt 2>&1
+timeout -k 10 300 python3 scripts/rollout_bench.py > $O/rollout_bench.txt 2>/dev/null
 rm -rf $O/pmc $O/benchprof profiles_tmp
 ls -la $O
