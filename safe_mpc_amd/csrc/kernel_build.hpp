@@ -99,6 +99,8 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS;
     constexpr int NSLOT = (MR_MAX + SB_G - 1) / SB_G;      // collision rows per lane (row g + 8 s on lane g)
     constexpr int NNL = SB_G - 1;                          // the lane that owns the network's row
+    static_assert(NQ < SB_G, "lane SB_G - 1 carries the network's row, lanes 0 .. NQ - 1 a joint each");
+    static_assert(MR_MAX <= 2 * SB_G && 2 * NQ <= 2 * SB_G, "at most two collision rows and two box rows per lane");
     using LD = SbLds<NQ, MR_MAX>;
     const int MR = Ly.MR, MRP = Ly.MRP;
     const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;
