@@ -12,7 +12,6 @@ O=$R/gpurun_out/r04
 rm -rf $O; mkdir -p $O
 cd $R
 bash scripts/prof_pmc.sh r04/pmc > $O/pmc.log 2>&1 && cp $O/pmc/pmc_traffic.json $O/pmc_traffic.json && cp $O/pmc/kernel_sheet.txt $O/kernel_sheet.txt
-mkdir -p profiles_tmp
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err
 bash scripts/prof_bench.sh r04/benchprof > /dev/null 2>&1
 cp $O/benchprof/kernel_stats.csv $O/bench_kernel_stats.csv; cp $O/benchprof/kernel_summary_by_grid.txt $O/bench_kernel_summary_by_grid.txt; cp $O/benchprof/bench_under_rocprof.json $O/bench_under_rocprof.json
@@ -34,5 +33,5 @@ SMPC_BENCH_CONTROLLER=constraint_everywhere timeout -k 10 300 python3 bench.py -
 timeout -k 10 300 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-survey-window > $O/bench_100steps.json 2>> $O/bench.err
 SMPC_STEPS=60 timeout -k 10 400 python3 scripts/policy_bench.py st htwa receding real_receding > $O/policy_bench.txt 2>&1
 timeout -k 10 300 python3 scripts/rollout_bench.py > $O/rollout_bench.txt 2>/dev/null
-rm -rf $O/pmc $O/benchprof profiles_tmp
+rm -rf $O/pmc $O/benchprof
 ls -la $O
