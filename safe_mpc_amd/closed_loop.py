@@ -474,6 +474,8 @@ class _Group(InPlaceState):
     def _read_times(self, j, final=False):
         """rows of the solves up to step j whose events have finished (device path: never the 32 most recent unless ``final``)"""
         sv = self._ctrl.ocp_solver
+        if final:
+            sv.sync()                              # end of the run: everything has finished, drain the ring
         while self._time_next <= j:
             back = j - self._time_next
             if back >= 64:                         # the ring has lapped it (the host ran more than 64 solves ahead of this read)
@@ -482,8 +484,8 @@ class _Group(InPlaceState):
                 continue
             if not final and back < 32:
                 break
-            if back >= 56 or final:
-                sv.sync()                          # about to be lapped / end of the run: wait rather than lose the row
+            if not final and back >= 56:
+                sv.sync()                          # about to be lapped: wait rather than lose the row
             tm = sv.timing_history(back)
             if tm is None:
                 if final:

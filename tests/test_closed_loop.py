@@ -177,3 +177,40 @@ def test_run_mpc_collects_solver_times_like_the_reference():
     assert np.allclose(res['time_q99'], np.quantile(ts, 0.99, axis=0))
     ref = cl.run_mpc(par, 'st', np.repeat(x0[:, None, :], 9, axis=1), np.zeros((4, 8, 6)), make_controller=mk, make_backup=mkb, n_steps=6)
     assert 'time_stats' not in ref and np.array_equal(ref['x'], res['x'])      # collecting times changes nothing else
+
+
+def test_event_ring_reader_never_loses_or_duplicates_a_solve():
+    """closed_loop._Group._read_times against a simulated 64-deep event ring (smpc_get_timing_history): solves finish a varying
+    number of steps after they were enqueued; the reader takes entries at least 32 solves old, waits (sync) rather than letting the
+    ring lap an unread entry, and drains the rest at the end -- every solve's row exactly once, in order."""
+    class Ring:
+        """solve j becomes readable once `done` > j; back = number of solves since"""
+        def __init__(self):
+            self.enq, self.done, self.syncs = 0, 0, 0
+
+        def timing_history(self, back):
+            j = self.enq - 1 - back
+            if back >= 64 or j < 0 or j >= self.done:
+                return None
+            return {'time_lin': 1e-3 * j, 'time_nn': 0.0, 'time_qp_setup': 0.0, 'time_qp_ipm': 2e-3, 'time_tot': 1.0 + j}
+
+        def sync(self):
+            self.syncs += 1
+            self.done = self.enq
+
+    for lag in (0, 5, 40, 100):                      # how far the GPU trails the host's enqueueing
+        ring = Ring()
+        g = cl._Group.__new__(cl._Group)
+        g._ctrl = type('C', (), {'ocp_solver': ring})()
+        g._time_rows, g._time_next, g._time_lost = [], 0, 0
+        n = 150
+        for j in range(n):
+            ring.enq = j + 1
+            ring.done = max(ring.done, j + 1 - lag)
+            g._read_times(j)
+        g._read_times(n - 1, final=True)
+        rows = np.array(g._time_rows)
+        assert g._time_lost == 0 and rows.shape == (n, 7), (lag, g._time_lost, rows.shape)
+        assert np.array_equal(rows[:, 6], 1.0 + np.arange(n))          # every solve once, in order
+        if lag <= 5:
+            assert ring.syncs == 1                                      # only the final drain waits
