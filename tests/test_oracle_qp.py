@@ -212,3 +212,44 @@ def test_stall_exit_gives_up_on_an_infeasible_tube_and_spares_feasible_solves():
     _, _, sb, ib = o0.solve_batch(x0, xg, ug, p)
     assert np.all(sa == 4) and np.all(sb == 4)                      # QP failure either way (controller.py:125,158 test for it)
     assert ia.max() <= 24 + 8 and ib.min() > ia.max()
+
+
+def test_oracle_ipm_on_late_closed_loop_qps_against_the_dense_solver():
+    """The oracle's interior point on QPs from the RUNNING closed loop (step 40), against tests/qp_ref.py (condensed dense QP,
+    log-barrier Newton, exit 1e-11): the objective within the duality-gap bound m x qp_tol of the dense optimum, the step feasible,
+    and -- re-solved with qp_tol = 1e-12 -- the controls within the bound the flat directions of the stage Hessian allow
+    (LM x dt = 2.5e-3: |dz| <= sqrt(2 m tol / 2.5e-3)).  The GPU suite runs the same check on the engine."""
+    from qp_ref import condense, solve_condensed
+    N, B = 30, 4
+    par, prob, net = make_problem('st', 'ext', N=N)
+    par_t, prob_t, _ = make_problem('st', 'ext', N=N, qp_tol=1e-12, qp_tol_res=1e-8)
+    o, ot = Oracle(prob, (net.weights, net.biases)), Oracle(prob_t, (net.weights, net.biases))
+    x = sample_instances(prob, B, seed=0)
+    xg, ug, p = constant_guess(prob, x)
+    fails = np.zeros(B, int)
+    for j in range(41):
+        xg = o.guess_correction(xg, ug)
+        xt, ut, st, it = o.solve_batch(x, xg, ug, p)
+        if j == 40:
+            xq, uq, sq, iq = ot.solve_batch(x, xg, ug, p)
+            assert np.all(st == 0) and np.all(sq == 0)
+            for b in range(B):
+                cq = condense(o.build_qp(x[b], xg[b], ug[b], p[b]), N, 6, par.dt)
+                v, _, _, nit = solve_condensed(cq)
+                assert nit < 150
+                sw, G, h = cq['soft_w'], cq['G'], cq['h']
+
+                def obj(w):
+                    r = G @ w - h
+                    return 0.5 * w @ cq['H'] @ w + cq['g'] @ w + np.sum(np.where(sw >= 0, sw * np.maximum(r, 0.0), 0.0))
+                du, dq = (ut[b] - ug[b]).reshape(-1), (uq[b] - ug[b]).reshape(-1)
+                m = G.shape[0] + int((sw >= 0).sum())
+                assert np.max(np.where(sw >= 0, -1.0, G @ du - h)) < 1e-9                    # hard rows hold
+                gap = obj(du) - obj(v)
+                assert -1e-9 * (1 + abs(obj(v))) < gap < 2 * m * 1e-8, (b, gap)
+                assert np.abs(du - v).max() < 5e-2 * (1 + np.abs(v).max())                    # the softness at the default exit
+                assert np.abs(dq - v).max() < 2e-3 * (1 + np.abs(v).max()), (b, np.abs(dq - v).max())
+                assert obj(dq) - obj(v) < 1e-7 * (1 + abs(obj(v)))      # (complementarity 1e-12, linear residuals 1e-8)
+        fails = np.where(st == 0, 0, fails + 1)
+        xg, ug, u = o.provide_control((fails == 0).astype(np.int32), xt, ut, xg, ug)
+        x, _ = o.plant_step(x, u)
