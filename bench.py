@@ -236,15 +236,19 @@ def launch_children(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # defaults = the window SURVEY 8(d) / BASELINE.md section 3 quote C1 on (10 warm-up + 100 timed steps): the closed loop gets
+    # more expensive with time, and the 3 + 20 window of rounds 1-4 flattered `value` by ~18 %
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=B_PER_GPU, help='instances per GPU')
     ap.add_argument('--graphs', type=int, default=0,
-                    help='1: replay each sub-batch step as a captured hipGraph (measured: no gain at 1-2 streams, see DESIGN.md)')
+                    help='1: replay each sub-batch step as a captured hipGraph (one host launch per sub-batch and step instead of '
+                         '~25; measured on one GPU: no gain, DESIGN.md section 7 -- kept for A/B runs on a node whose ranks share '
+                         'the host; legal under torch.distributed: the log slot comes from a device-side step counter)')
     ap.add_argument('--streams', type=int, default=3,
                     help='sub-batches per GPU, each on its own HIP stream: independent instances, so the sub-batches advance '
-                         'independently and the long tail of one QP launch overlaps the bulk of another (measured r2: 1: 5.0, '
-                         '2: 4.3, 3: 3.9, 4: 4.7 ms per step)')
+                         'independently and the long tail of one QP launch overlaps the bulk of another (round 4, DESIGN.md '
+                         'section 8: 2 / 3 / 4 / 5 / 6 streams = 3.15 / 2.92 / 3.17 / 3.22 / 3.14 ms per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--noise', type=float, default=0.0,
                     help='model noise in percent (BASELINE config 2): per-instance perturbed plants, 256 distinct draws of '
@@ -327,7 +331,7 @@ def main():
     # log -- straight from the engine's kernels (u_out / status pointers of smpc_policy_step), no copy -- and ONE gather of the
     # log ends the timed region ("once per step ... or once per rollout").  A per-step collective would need an
     # event hand-off between the sub-batch streams and the collective's stream every step; measured on one GPU that
-    # re-synchronises the streams and costs 0.5-1.5 ms of the 3.9 ms step even with the collective itself skipped.
+    # re-synchronises the streams and costs 0.5-1.5 ms per step (round 2, on a 3.9 ms step) even with the collective itself skipped.
     K_log = max(args.steps, 1)
     log_bytes = K_log * B * (nu * 8 + 4)
     gather_in = torch.empty((log_bytes,), dtype=torch.uint8, device=dev)
@@ -355,6 +359,8 @@ def main():
             sb.jt = t(jt_all[lo:hi]) if jt_all is not None else None
             sb.tn = t(tn_all[lo:hi]) if tn_all is not None else None
             sb.status_home = sb.ctrl.last_status
+            sb.u_stage = torch.empty((sb.n, nu), dtype=torch.float64, device=dev)       # (--graphs 1: the step's control before it
+            sb.slot_dev = torch.zeros((1,), dtype=torch.int64, device=dev)             #  is copied to log row slot_dev)
         sb.tsum, sb.tcnt = np.zeros(5), 0
         subs.append(sb)
     if args.scaling == 'strong':
@@ -372,16 +378,23 @@ def main():
         slot is fixed).  <Controller>.step = guessCorrection, RTI solve, accept test, provideControl (controller.py:274-284 for
         'st'; :651-661 for 'constraint_everywhere') as smpc_policy_step; then the plant (env_model.py:192-206)."""
         sv, ctrl = sb.solver, sb.ctrl
-        fixed = bool(args.graphs)            # (--graphs 1: a captured step bakes its addresses in -- one log slot, state copied back)
-        slot = 0 if fixed else step_no[0] % K_log
-        u_slot = u_log[slot, sb.off:sb.off + sb.n]
-        if use_dist:      # the status of this step lands in the rollout log as well
-            object.__setattr__(ctrl, 'last_status', st_log[slot, sb.off:sb.off + sb.n])
-        ctrl.step_on_device(sb.x_sim, u_out=u_slot)
-        sv.plant_step(sb.x_sim, u_slot, sb.jt, sb.tn, out=(sb.x_next, sb.u_eff))
+        fixed = bool(args.graphs)            # (--graphs 1: a captured step bakes its addresses in -- state copied back, and the
+                                             #  log slot taken from a device-side step counter instead of the host's)
         if fixed:
+            ctrl.step_on_device(sb.x_sim, u_out=sb.u_stage)
+            sv.plant_step(sb.x_sim, sb.u_stage, sb.jt, sb.tn, out=(sb.x_next, sb.u_eff))
             sb.x_sim.copy_(sb.x_next)
+            # rollout log: row `slot_dev` of this sub-batch's columns, then slot_dev = (slot_dev + 1) mod K_log -- all on the device
+            u_log[:, sb.off:sb.off + sb.n].index_copy_(0, sb.slot_dev, sb.u_stage.unsqueeze(0))
+            st_log[:, sb.off:sb.off + sb.n].index_copy_(0, sb.slot_dev, ctrl.last_status.unsqueeze(0))
+            sb.slot_dev.add_(1).remainder_(K_log)
         else:
+            slot = step_no[0] % K_log
+            u_slot = u_log[slot, sb.off:sb.off + sb.n]
+            if use_dist:      # the status of this step lands in the rollout log as well
+                object.__setattr__(ctrl, 'last_status', st_log[slot, sb.off:sb.off + sb.n])
+            ctrl.step_on_device(sb.x_sim, u_out=u_slot)
+            sv.plant_step(sb.x_sim, u_slot, sb.jt, sb.tn, out=(sb.x_next, sb.u_eff))
             sb.x_sim, sb.x_next = sb.x_next, sb.x_sim
         sv.accumulate_stats(ctrl.last_status, ctrl.qp_iter, sb.acc)
 
@@ -421,7 +434,7 @@ def main():
     # hipGraph capture of one sub-batch step (after the warm-up: every workspace exists, nothing allocates or syncs).
     # With S sub-batches in flight the host has to issue S x 25 launches per step; as graphs that is S launches, and the
     # streams drift apart so that the long tail of one sub-batch's QP kernel is filled by the bulk of another's.
-    if args.graphs and args.warmup >= 2 and not use_dist:      # (the captured step bakes in one slot of the rollout log)
+    if args.graphs and args.warmup >= 2:
         try:
             for sb in subs:
                 g = torch.cuda.CUDAGraph()
@@ -437,11 +450,17 @@ def main():
         with torch.cuda.stream(sb.stream):
             sb.acc.zero_()
     # (the timed region runs uninstrumented: no HIP events inside it.  kernel_ms_in_loop comes from a pass of its own, below)
+    for sb in subs:
+        with torch.cuda.stream(sb.stream):
+            sb.slot_dev.zero_()
     barrier()
     t0 = time.perf_counter()
     step_no[0] = 0
     for i in range(args.steps):
         step(first=(args.warmup == 0 and i == 0))
+    # what the host spent enqueueing the timed steps (~25 launches per sub-batch and step, from Python): when this approaches
+    # ms_per_step the loop is bound by the host, not by the GPU -- the thing to look at first when 8 ranks share one host
+    host_issue = time.perf_counter() - t0
     if use_dist:
         gather_results()
     barrier()

@@ -55,23 +55,26 @@ def perturbed_joint_tables(params, nq, noise_pct, seeds):
     1 + U(-noise, noise)% (utils.py:138-166) BEFORE lumping -- in memory, instead of one URDF file per instance."""
     base = params.robot_descr
     out = np.zeros((len(seeds), nq), JOINT_DTYPE)
+    # The reference draws uniform(-n, n) for EVERY field, also where the field and hence n is zero (ixy = 0 ...): the draw returns 0
+    # but advances the generator, so a replay of its seeded perturbations needs the same.  Default (reference_quirks); without it
+    # zero-magnitude fields consume nothing (rounds 1-4).
+    always_draw = bool(getattr(params, 'reference_quirks', True))
     for row, seed in enumerate(seeds):
         rng = np.random.default_rng(int(seed))
+        draw = lambda n_: rng.uniform(-n_, n_) if (n_ > 0 or (always_draw and noise_pct > 0)) else 0.0
         links = []
         for l in base.links:
             l2 = copy.copy(l)
             if l.inertial is not None:
                 m = l.inertial.mass
-                m = m + rng.uniform(-abs(m) * noise_pct / 100, abs(m) * noise_pct / 100) if noise_pct > 0 else m
+                m = m + draw(abs(m) * noise_pct / 100)
                 I = l.inertial.inertia.copy()
-                for (a, b) in [(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (0, 2)]:       # ixx iyy izz ixy iyz ixz
-                    n_ = abs(I[a, b]) * noise_pct / 100
-                    v = I[a, b] + (rng.uniform(-n_, n_) if n_ > 0 else 0.0)
+                for (a, b) in [(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (0, 2)]:       # ixx iyy izz ixy iyz ixz (utils.py:128)
+                    v = I[a, b] + draw(abs(I[a, b]) * noise_pct / 100)
                     I[a, b] = I[b, a] = v
                 xyz = l.inertial.origin.xyz.copy()
                 for k in range(3):
-                    n_ = abs(xyz[k] * noise_pct / 100)
-                    xyz[k] += rng.uniform(-n_, n_) if n_ > 0 else 0.0
+                    xyz[k] += draw(abs(xyz[k] * noise_pct / 100))
                 l2.inertial = Inertial(Origin(xyz, l.inertial.origin.rpy), m, I)
             links.append(l2)
         chain = SerialChain(RobotDescription(links, base.joints, base.name), nq)
@@ -454,6 +457,9 @@ class _Group(InPlaceState):
 
     def _run_half(self, half, fn, j):
         """eager for the first steps (workspaces get allocated), then captured once per code path and replayed"""
+        if getattr(self._ctrl, '_traj_rebound', False):      # setTrajectory bound a new device tensor: captured steps hold the old one
+            self._graphs.clear()
+            self._ctrl._traj_rebound = False
         key = (half, self._ever_aborted)
         g = self._graphs.get(key)
         if g is None and self._use_graphs and j >= 3 and key not in self._graphs:
@@ -498,6 +504,19 @@ class _Group(InPlaceState):
 
     def run(self):
         """generator: yields once per step, after the first half is enqueued (run_mpc serves the other groups meanwhile)"""
+        try:
+            yield from self._run()
+        finally:
+            # whatever path ran (device loop, host state on the HIP engine, an exception in between): the handle stops recording
+            # events when the run is over
+            sv = self._ctrl.ocp_solver
+            if self._collect_times and hasattr(sv, 'enable_timing'):
+                try:
+                    sv.enable_timing(0)
+                except Exception:
+                    pass
+
+    def _run(self):
         xp = self._xp
         for j in range(self._n_steps):
             self._run_half('a', self.part_a, j)
@@ -518,7 +537,6 @@ class _Group(InPlaceState):
             self._apply_inflight()            # (events of the last step)
         if self._collect_times and xp.on_device:
             self._read_times(self._n_steps - 1, final=True)
-            self._ctrl.ocp_solver.enable_timing(0)
 
     def results(self):
         xp, ctrl, params, B, n_steps = self._xp, self._ctrl, self._params, self._B, self._n_steps

@@ -92,7 +92,20 @@ class AbstractController(InPlaceState):
         traj = np.ascontiguousarray(traj, float)
         if traj.ndim != 2 or traj.shape[0] != 3 or traj.shape[1] < 1:
             raise ValueError('traj must be [3, n_columns]')
-        self.traj = self.xp.asarray(traj, self.xp.f64)
+        # the reference indexes cost.traj[:, current_step + i] for i <= N over a run of n_steps steps and would raise on a shorter
+        # array; here the column index is clamped (the device kernel must not read past the end), so say so instead of silently
+        # holding the last point
+        need = int(getattr(self.params, 'n_steps', 0)) + 1 + self.N
+        if traj.shape[1] < need:
+            import warnings
+            warnings.warn(f'setTrajectory: {traj.shape[1]} columns < n_steps + 1 + N = {need}: the reference would fail with an '
+                          'IndexError past the end; this engine holds the last column', RuntimeWarning, stacklevel=2)
+        new = self.xp.asarray(traj, self.xp.f64)
+        if self.traj is not None and tuple(self.traj.shape) == tuple(new.shape):
+            self.traj[...] = new       # in place: a captured step (hipGraph) keeps the device pointer and length it was captured with
+        else:
+            self.traj = new
+            self._traj_rebound = True  # (closed_loop._Group drops its captured graphs when it sees this)
 
     def _apply_traj(self, rows=None):
         """p[b, i, 0:3] = traj[:, current_step[b] + i] (controller.py:153-156)"""

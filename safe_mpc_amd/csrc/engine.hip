@@ -44,12 +44,14 @@ struct smpc_handle {
     // per-batch scratch, grown on demand
     int capB = 0;
     double* d_ev = nullptr;       // linearisation records of the last call, interleaved tiles of EV_TILE nodes (device_model.hpp)
-    double* d_nn = nullptr;       // [B][N+1][1 + nx]: value and gradient of the network's row per node (read by the stage builder)
+    double* d_nn = nullptr;       // value and gradient of the network's row (read by the stage builder): [B][N+1][1 + nx] with the row
+                                  // on every node, [B][1 + nx] with the row on the end node only, not allocated without a network row
     bool ev_new_order[64] = {};   // per slot of the event ring: the solve ran MLP -> stage builder (ev1, ev2 swap their meaning)
     double* d_ws = nullptr;
     size_t ws_bytes = 0;
     int32_t *d_order = nullptr, *d_last_it = nullptr;  // longest-first dispatch order from the previous call's iterations
     int order_B = 0;                                   // batch size d_last_it is valid for (0 = none yet)
+    int32_t* d_ord_hist = nullptr;                     // [256] histogram of d_last_it (k_qp_ipm) | [256] bin cursors | ticket (k_order_by_iters)
     // staging for host-pointer calls
     int capIO = 0;
     double *d_x0 = nullptr, *d_xg = nullptr, *d_ug = nullptr, *d_p = nullptr, *d_xo = nullptr, *d_uo = nullptr;
@@ -155,11 +157,16 @@ int ensure_batch(smpc_handle* h, int B) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if ((rc = dev_alloc(h, &h->d_ev, ev_tiles((size_t)B * (h->N + 1)) * EV_TILE * EV_D))) return rc;
         if ((rc = dev_alloc(h, &h->d_ws, per * (size_t)B))) return rc;
-        if ((rc = dev_alloc(h, &h->d_nn, (size_t)B * (h->N + 1) * (1 + 2 * h->desc.nq)))) return rc;
-        // (entries beyond n_dof_safe_set are never written and must read as zero)
-        HIPCHK(h, hipMemsetAsync(h->d_nn, 0, sizeof(double) * (size_t)B * (h->N + 1) * (1 + 2 * h->desc.nq), h->stream));
+        {
+            const size_t nn_nodes = h->desc.nn_mode == SMPC_NN_NONE ? 0 : (h->desc.nn_mode == SMPC_NN_TERMINAL ? (size_t)B : (size_t)B * (h->N + 1));
+            if ((rc = dev_alloc(h, &h->d_nn, nn_nodes * (1 + 2 * h->desc.nq)))) return rc;
+            // (entries beyond n_dof_safe_set are never written and must read as zero)
+            if (nn_nodes) HIPCHK(h, hipMemsetAsync(h->d_nn, 0, sizeof(double) * nn_nodes * (1 + 2 * h->desc.nq), h->stream));
+        }
         if ((rc = dev_alloc(h, &h->d_order, (size_t)B))) return rc;
         if ((rc = dev_alloc(h, &h->d_last_it, (size_t)B))) return rc;
+        if ((rc = dev_alloc(h, &h->d_ord_hist, (size_t)520))) return rc;
+        HIPCHK(h, hipMemsetAsync(h->d_ord_hist, 0, 520 * sizeof(int32_t), h->stream));
         h->order_B = 0;
         h->ws_bytes = need;
         h->capB = B;
@@ -380,7 +387,7 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
     // a stream's chain pays for them inside the loop (bit 0: linearisation, bit 1: set-up; old path only)
     static const int dup = [] { const char* e = getenv("SMPC_DUP_KERNELS"); return e ? atoi(e) : 0; }();
     if (path == 1) {
-        if ((rc = launch_nn<NQ>(h, B, xg, p, h->d_nn, 1))) return rc;
+        if ((rc = launch_nn<NQ>(h, B, xg, p, h->d_nn, h->desc.nn_mode == SMPC_NN_TERMINAL ? 2 : 1))) return rc;
         if (timed) HIPCHK(h, hipEventRecord(h->ev_t[1], h->stream));
         const long nodes = (long)B * (h->N + 1);
         const dim3 grd((unsigned)((nodes + 64 / SB_G - 1) / (64 / SB_G))), blk(64);
@@ -448,8 +455,12 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     if ((rc = launch_stage_records<NQ>(h, B, x0, xg, ug, p, timed, path))) return rc;
     const int32_t* order = nullptr;
     if (h->order_B == B && B > 1) {
-        hipLaunchKernelGGL(k_order_by_iters, dim3(1), dim3(1024), 0, h->stream, B, h->d_last_it, h->d_order);
+        hipLaunchKernelGGL(k_order_by_iters, dim3((B + ORD_PER_BLOCK - 1) / ORD_PER_BLOCK), dim3(64), 0, h->stream, B, h->d_last_it,
+                           h->d_order, h->d_ord_hist, h->d_ord_hist + 256, h->d_ord_hist + 512);
         order = h->d_order;
+    } else {
+        // (no order this time: the histogram k_qp_ipm adds to must hold this solve alone when the next one sorts by it)
+        HIPCHK(h, hipMemsetAsync(h->d_ord_hist, 0, 520 * sizeof(int32_t), h->stream));
     }
     unsigned long long* wstat = nullptr;
     if (timed && h->timing == 1) {      // (timing mode 2: events only, no in-kernel load-balance probe)
@@ -462,7 +473,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     const bool nt = qp_nt_mode() < 0 ? ws_doubles_per_instance(h->desc, h->N) * sizeof(double) * (size_t)B >= qp_nt_threshold : qp_nt_mode() > 0;
 #define SMPC_QP_LAUNCH(MR_, NT_)                                                                                                   \
     hipLaunchKernelGGL((k_qp_ipm<NQ, MR_, NT_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,  \
-                       ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active)
+                       ug, h->d_ws, xo, uo, st, it, order, h->d_last_it, wstat, h->d_active, h->d_ord_hist)
     switch (h->desc.n_rows) {
     case 6: if (nt) SMPC_QP_LAUNCH(6, true); else SMPC_QP_LAUNCH(6, false); break;
     case 4: if (nt) SMPC_QP_LAUNCH(4, true); else SMPC_QP_LAUNCH(4, false); break;
@@ -660,7 +671,7 @@ void smpc_destroy(smpc_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    void* ptrs[] = {h->d_desc, h->d_zl, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_nn, h->d_ws, h->d_order, h->d_last_it, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
+    void* ptrs[] = {h->d_desc, h->d_zl, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_nn, h->d_ws, h->d_order, h->d_last_it, h->d_ord_hist, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
                     h->d_st, h->d_it, h->d_S, h->d_y, h->d_GS, h->d_dA, h->d_dB, h->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < SMPC_MAX_LAYERS; l++) {

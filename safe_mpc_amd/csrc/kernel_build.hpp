@@ -226,8 +226,10 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
     // composites: suffix sums over the lanes of the group (lane g <- bodies g .. NQ-1)
     auto scan_step = [&](auto off_tag) {
         constexpr int OFF = decltype(off_tag)::value;
-        const double take = g + OFF < SB_G ? 1.0 : 0.0;          // (the neighbour node's lanes share the row of 16)
-        auto acc = [&](double& x) { x = fma(dpp_up<OFF>(x), take, x); };
+        // (the neighbour node's lanes share the row of 16: a select, not a multiplication by zero -- a NaN or Inf in the other
+        //  node's composites must not reach this node's)
+        const bool take = g + OFF < SB_G;
+        auto acc = [&](double& x) { const double up = dpp_up<OFF>(x); x = take ? x + up : x; };
         acc(Yc.m); acc(Yc.mc.x); acc(Yc.mc.y); acc(Yc.mc.z);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc(Yc.I[i]);
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SB_WAVES, SB
     const double* pk = pp + ((size_t)b * (N + 1) + k) * SMPC_NP;
     const size_t bo = (size_t)b * bnd_stride + (size_t)k * NX;
     stage_build<NQ, MRT>(D, Ly, N, k, valid, g, smem + grp * LD::SIZE, x0 + (size_t)b * NX, xk, uk, pk, lo_st + bo, hi_st + bo, zl_st,
-                         nn ? nn + ((size_t)b * (N + 1) + k) * (1 + NX) : nullptr, w);
+                         nn ? nn + (D->nn_mode == SMPC_NN_TERMINAL ? (size_t)b : (size_t)b * (N + 1) + k) * (1 + NX) : nullptr, w);
 }
 
 }  // namespace smpc

@@ -126,14 +126,13 @@ template <int NQ> struct QpLayout {
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
-// Cache policy of the stage-workspace accesses, selectable at build time (-DSMPC_NT_MASK=...).  The workspace is a stream:
-// every block is touched once per sweep by one wavefront and comes round again a millisecond later, long after the 4 MB L2
-// of its XCD has turned over, so non-temporal (`nt`) accesses look right -- and for ONE launch over the whole batch they are:
-// nt on the wide loads and on the factorisation sweep's wide stores (mask 0x3) takes 8.5 % off k_qp_ipm (2.85 -> 2.62 ms at 5
-// forced iterations, A/B in one session; narrow 8-byte nt loads +6 %, k_qp_setup's stores no gain).  In the closed-loop
-// bench, where three sub-batch launches and their linearisation / set-up kernels share the chip, the same build is 4 %
-// SLOWER (4.02 vs 3.86 ms per step, three alternations) -- the sub-batch workspaces (278 MB each) partly live in the
-// 256 MB Infinity Cache between a set-up and its first sweeps, and nt gives that up.  Shipped default: 0 (plain accesses).
+// Cache policy of the stage-workspace accesses.  The workspace is a stream: every block is touched once per sweep by one
+// wavefront and comes round again a millisecond later, long after the 4 MB L2 of its XCD has turned over.  Whether non-temporal
+// (`nt`) accesses pay depends on the workspace's size against the 256 MB Infinity Cache, so k_qp_ipm is built both ways
+// (template parameter NT: nt on its wide loads and on the factorisation sweep's wide stores) and the engine picks PER LAUNCH
+// (engine.hip: qp_nt_threshold; measurements at the kernel, below).  SMPC_NT_MASK is the build-time override of rounds 2-3, kept
+// for experiments on the remaining access classes (narrow 8-byte nt loads measured +6 %, k_qp_setup's stores no gain); its
+// default 0 leaves everything but the NT template's accesses plain.
 #ifndef SMPC_NT_MASK
 #define SMPC_NT_MASK 0x0
 #endif
@@ -588,7 +587,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const smpc_problem_desc* __restrict__ D, int B, int N, const double* __restrict__ x0, const double* __restrict__ xg,
     const double* __restrict__ ug, double* __restrict__ ws_all, double* __restrict__ x_out, double* __restrict__ u_out,
     int32_t* __restrict__ status, int32_t* __restrict__ qp_iter, const int32_t* __restrict__ order,
-    int32_t* __restrict__ last_iter, unsigned long long* __restrict__ wstat, const uint8_t* __restrict__ active) {
+    int32_t* __restrict__ last_iter, unsigned long long* __restrict__ wstat, const uint8_t* __restrict__ active,
+    int32_t* __restrict__ it_hist) {
     using LyT = QpLayout<NQ>;
     constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NL = 32,
                   LC0 = LyT::LC0, KS = LyT::KS, NWP = LyT::NWP;
@@ -633,6 +633,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             status[b] = SMPC_STATUS_SUCCESS;
             if (qp_iter) qp_iter[b] = 0;
             if (last_iter) last_iter[b] = 0;
+            if (it_hist) atomicAdd(&it_hist[0], 1);
         }
         return;
     }
@@ -1554,26 +1555,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         status[b] = stc;
         if (qp_iter) qp_iter[b] = it;
         if (last_iter) last_iter[b] = it;
+        if (it_hist) atomicAdd(&it_hist[min(it, 255)], 1);   // next solve's longest-first order (k_order_by_iters)
     }
 }
 
 
-// order[] = instance indices sorted by decreasing previous iteration count (counting sort, one block)
-__global__ __launch_bounds__(1024) void k_order_by_iters(int B, const int32_t* __restrict__ last_iter, int32_t* __restrict__ order) {
-    __shared__ int hist[256], offs[256];
+// order[] = instance indices sorted by decreasing previous iteration count: a counting sort over ONE-WAVE blocks (a block of
+// another stream's kernel only starts where a wavefront slot is free; the single 1024-thread block of rounds 1-4 needed a whole CU
+// without QP wavefronts and waited 3.4 ms on average, 30 ms at worst, at 65 536 instances: profiles/r04_c2_kernel_summary_by_grid.txt).
+// The histogram hist[256] of the iteration counts is accumulated by k_qp_ipm itself as its half-waves retire; every block here
+// turns it into bin offsets (256 adds), takes positions inside a bin from the global cursors cur[256], and the last block to
+// finish clears hist, cur and the ticket for the next solve (no parity, nothing baked into a captured graph).  The order inside
+// a bin is arbitrary (as before): instances are independent, the order only changes the makespan.
+constexpr int ORD_PER_BLOCK = 256;
+__global__ __launch_bounds__(64) void k_order_by_iters(int B, const int32_t* __restrict__ last_iter, int32_t* __restrict__ order,
+                                                       int32_t* __restrict__ hist, int32_t* __restrict__ cur, int32_t* __restrict__ ticket) {
+    __shared__ int offs[256];
     const int t = threadIdx.x;
-    if (t < 256) hist[t] = 0;
-    __syncthreads();
-    for (int i = t; i < B; i += 1024) atomicAdd(&hist[min(max(last_iter[i], 0), 255)], 1);
-    __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int v = 255; v >= 0; v--) { offs[v] = acc; acc += hist[v]; }
+    {
+        // offs[v] = number of instances with more than v iterations: a suffix sum over 256 bins, four bins per lane
+        int h4[4], run = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; j--) { h4[j] = hist[4 * t + j]; }
+        int mine = h4[0] + h4[1] + h4[2] + h4[3];
+        // inclusive suffix scan of `mine` over the 64 lanes (lane t needs the sum over lanes > t)
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_down(incl, o);
+            if (t + o < 64) incl += v;
+        }
+        run = incl - mine;                        // bins of the lanes above
+#pragma unroll
+        for (int j = 3; j >= 0; j--) { offs[4 * t + j] = run; run += h4[j]; }
     }
     __syncthreads();
-    for (int i = t; i < B; i += 1024) {
-        const int v = min(max(last_iter[i], 0), 255);
-        order[atomicAdd(&offs[v], 1)] = i;
+    const int i0 = blockIdx.x * ORD_PER_BLOCK;
+#pragma unroll
+    for (int j = 0; j < ORD_PER_BLOCK / 64; j++) {
+        const int i = i0 + 64 * j + t;
+        if (i < B) {
+            const int v = min(max(last_iter[i], 0), 255);
+            const int pos = offs[v] + atomicAdd(&cur[v], 1);
+            if (pos < B) order[pos] = i;          // (always true when hist holds exactly the last solve of this batch)
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (t == 0) offs[0] = atomicAdd(ticket, 1);
+    __syncthreads();
+    if (offs[0] == (int)gridDim.x - 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { hist[4 * t + j] = 0; cur[4 * t + j] = 0; }
+        if (t == 0) *ticket = 0;
     }
 }
 

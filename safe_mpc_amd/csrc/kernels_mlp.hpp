@@ -294,7 +294,8 @@ __global__ void k_nn_chain(const smpc_problem_desc* __restrict__ D, int M, int N
     const double* pk = p + node * SMPC_NP;
     // compact: out is nn[node][1 + 2 NQ] = (value, gradient) -- what k_stage_build / the QP's stage builder read; otherwise the
     // node's linearisation record (interleaved tile: element f at o[f * EV_TILE])
-    double* const o = compact ? out + node * (1 + 2 * NQ) : ev_node(out, node);
+    // (compact = 2, the row on the end node only: nn[instance][1 + 2 NQ], a buffer (N + 1) times smaller)
+    double* const o = compact ? out + (compact == 2 ? node / (N + 1) : node) * (1 + 2 * NQ) : ev_node(out, node);
     const long es = compact ? 1 : EV_TILE;
     const int o_val = compact ? 0 : SMPC_EV_OFF(nn_val), o_grad = compact ? 1 : SMPC_EV_OFF(nn_grad);
     if (!(pk[4] > 0.0)) return;  // switched off: row sits mid-bounds, leave (0, 0)
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const smpc_problem_desc* __re
         const double* x = xg + node * (2 * NQ);
         const double* pk = p + node * SMPC_NP;
         if (pk[4] > 0.0) {                                   // (switched off: the row sits mid-bounds, (0, 0) is left)
-            double* const o = compact ? ev_out + node * (1 + 2 * NQ) : ev_node(ev_out, node);      // (see k_nn_chain)
+            double* const o = compact ? ev_out + (compact == 2 ? node / (N + 1) : node) * (1 + 2 * NQ) : ev_node(ev_out, node);      // (see k_nn_chain)
             const long es = compact ? 1 : EV_TILE;
             const int o_val = compact ? 0 : SMPC_EV_OFF(nn_val), o_grad = compact ? 1 : SMPC_EV_OFF(nn_grad);
             const int nd = D->nn_dof;

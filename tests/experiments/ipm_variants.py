@@ -1,0 +1,83 @@
+"""CPU experiment (oracle only, not product): variants of the IPM iteration that move fewer bytes per solve.
+Closed loop of the oracle; per variant: mean IPM iterations, iterations whose corrector (sweeps B2 + F2) was skipped, the cost of a
+solve in units of one full iteration's workspace traffic (B1 + F1 = 0.64, B2 + F2 = 0.36 of the 1857 doubles per stage and
+iteration), the mean of the per-step maxima (what sets a launch's duration), failed solves and the deviation of
+the closed-loop trajectory from the baseline's.
+usage: python tests/experiments/ipm_variants.py [problem: st | constraint_everywhere | fr7 | ...] [B] [steps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from conftest import make_problem, make_problem_fr7, sample_instances, constant_guess
+from oracle.oracle import Oracle
+
+PROB = sys.argv[1] if len(sys.argv) > 1 else 'st'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+C_HALF = float(os.environ.get('C_HALF', 0.64))     # cost of an iteration without corrector
+
+
+def setup():
+    if PROB == 'fr7':
+        par, prob, net = make_problem_fr7()
+    else:
+        par, prob, net = make_problem(PROB, 'ext', N=30)
+    return par, prob, net
+
+
+def run(env):
+    for k in list(os.environ):
+        if k.startswith('SMPC_ORACLE_X_'):
+            del os.environ[k]
+    os.environ.update({'SMPC_ORACLE_X_' + k: str(v) for k, v in env.items()})
+    par, prob, net = setup()
+    o = Oracle(prob, (net.weights, net.biases))
+    x = sample_instances(prob, B, seed=0)
+    xg, ug, p = constant_guess(prob, x)
+    fails = np.zeros(B, int)
+    X, IT, SK, nfail = [x.copy()], [], [], 0
+    for j in range(STEPS):
+        xg = o.guess_correction(xg, ug)
+        xt, ut, st, it = o.solve_batch(x, xg, ug, p)
+        IT.append(it % 1000)
+        SK.append(it // 1000)
+        nfail += int((st != 0).sum())
+        fails = np.where(st == 0, 0, fails + 1)
+        xg, ug, u = o.provide_control((fails == 0).astype(np.int32), xt, ut, xg, ug)
+        x, _ = o.plant_step(x, u)
+        X.append(x.copy())
+    return np.array(X), np.array(IT), np.array(SK), nfail
+
+
+VARIANTS = [
+    ('baseline', {}),
+    ('affine exit', {'AFFEXIT': 1}),
+    ('skip a>=.95 r<=.1', {'AFFEXIT': 1, 'SKIP_A': 0.95, 'SKIP_R': 0.1}),
+    ('skip a>=.9 r<=.15', {'AFFEXIT': 1, 'SKIP_A': 0.9, 'SKIP_R': 0.15}),
+    ('skip a>=.8 r<=.25', {'AFFEXIT': 1, 'SKIP_A': 0.8, 'SKIP_R': 0.25}),
+    ('no 2nd-order term', {'NO2ND': 1}),
+    ('ftb .999', {'FTB': 0.999}),
+    ('sigma cap .1', {'SIGCAP': 0.1}),
+    ('sigma pow 2', {'SIGPOW': 2}),
+    ('sigma pow 4', {'SIGPOW': 4}),
+    ('cw a^2', {'CWMODE': 1}),
+    ('cw a', {'CWMODE': 2}),
+    ('ftb .9995', {'FTB': 0.9995}),
+    ('ftb gate .9', {'FTBGATE': 0.9}),
+    ('ftb gate .5', {'FTBGATE': 0.5}),
+    ('ftb gate .9 ftb .999', {'FTBGATE': 0.9, 'FTB': 0.999}),
+    ('ftb hi .999999', {'FTBHI': 0.999999}),
+]
+if len(sys.argv) > 4:
+    VARIANTS = [VARIANTS[0]] + [v for v in VARIANTS if any(a in v[0] for a in sys.argv[4:])]
+
+base = None
+print(f'problem {PROB}, B = {B}, {STEPS} closed-loop steps; cost of an iteration without corrector = {C_HALF}')
+print(f'{"variant":22s} | mean it | skipped | cost/solve | vs base | mean step-max it | step-max cost | fails | max |x - x_base|')
+for name, env in VARIANTS:
+    X, IT, SK, nf = run(env)
+    cost = (IT - SK) + C_HALF * SK
+    if base is None:
+        base, c0 = X, cost.mean()
+    print(f'{name:22s} | {IT.mean():7.3f} | {SK.mean():7.3f} | {cost.mean():10.3f} | {cost.mean() / c0:7.3f} | {IT.max(1).mean():16.2f} | '
+          f'{cost.max(1).mean():13.2f} | {nf:5d} | {np.abs(X - base).max():.2e}', flush=True)
