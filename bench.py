@@ -470,6 +470,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     acc_all = sum(sb.acc.cpu().numpy().astype(np.int64) for sb in subs)
+    log_check = None
+    if os.environ.get('SMPC_BENCH_CHECK_LOG') == '1' and use_dist:
+        # (test hook: every timed step must have left its own row in the rollout log -- with --graphs 1 the row index is the
+        #  device-side counter's)
+        ul, sl = u_log.cpu().numpy(), st_log.cpu().numpy()
+        distinct = len({ul[k].tobytes() for k in range(K_log)})
+        log_check = (f'ok: {distinct} distinct log rows, statuses all zero' if distinct == K_log and not sl.any()
+                     else f'BAD: {distinct} distinct rows of {K_log}, {int((sl != 0).sum())} non-zero statuses')
     # Per-kernel HIP-event durations of the loop's own launches: the SAME loop continued for a few more steps with the engine's
     # event ring switched on (5 hipEventRecord per solve), outside the timed region -- `value` is measured without them.  The
     # per-solve `time_tot` of this pass is also what the reference reports per step (scripts/mpc.py:239,300-303).
@@ -553,9 +561,9 @@ def main():
         # the iterations it runs); traffic of THIS probe launch = that x the probe's own iteration count x instances, so that
         # traffic / kernel time is the rate of the launch that was timed here.  null when there is no file for this round's kernel.
         traffic, traffic_rate, traffic_src, bpi = None, None, None, None
-        for name in ('r04_pmc_traffic.json',):
+        for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json'):
             tf = os.path.join(ROOT, 'profiles', name)
-            if os.path.exists(tf) and CONTROLLER == 'st':
+            if bpi is None and os.path.exists(tf) and CONTROLLER == 'st':
                 tj = json.load(open(tf))
                 bpi = tj.get('bytes_per_instance_iteration')
                 if bpi:
@@ -592,7 +600,11 @@ def main():
     # same loop is run once more over exactly that window -- from the same initial state, after everything above, outside the
     # timed region that `value` reports -- and added to the line.
     survey = None
-    if world == 1 and not args.no_survey_window and not args.graphs and (args.steps, args.warmup) != (100, 10):
+    if (args.steps, args.warmup) == (100, 10):
+        survey = {'steps': 100, 'warmup': 10, 'ms_per_step': 1e3 * elapsed / 100, 'value': B_total * 100 / elapsed,
+                  'mean_ipm_iterations': mean_iter, 'failed_instance_steps': fails,
+                  'note': 'the window SURVEY 8(d) quotes C1 on IS this run\'s timed region (the default since round 5)'}
+    elif world == 1 and not args.no_survey_window and not args.graphs:
         for sb in subs:
             with torch.cuda.stream(sb.stream):
                 lo, hi = sb.off, sb.off + sb.n
@@ -620,13 +632,18 @@ def main():
 
     if rank == 0:
         total = B_total * args.steps
+        # BASELINE.json's configs by BOTH of their defining properties: C1 = 4096 instances without model noise, C2 = 65 536 with it
+        if args.noise > 0:
+            workload_tag = 'C2' if args.batch == 65536 else f'C2-like (model noise, {args.batch} instead of 65536 instances)'
+        else:
+            workload_tag = 'C1' if args.batch == B_PER_GPU else f'C1-like ({args.batch} instead of {B_PER_GPU} instances)'
         line = {
             'metric': 'RTI-MPC instance-steps/s (batch=4096 per GPU, Z1 N=30)' if args.scaling == 'weak' else
                       'RTI-MPC instance-steps/s (batch=4096 in total, Z1 N=30)',
             'value': total / elapsed, 'unit': 'instance-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True,
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': ('C2' if args.noise > 0 else 'C1') + f': Z1-class 6-DoF, N=30, {args.batch} instances' + ('/GPU' if args.scaling == 'weak' else ' in total') +
+            'config': {'workload': workload_tag + f': Z1-class 6-DoF, N=30, {args.batch} instances' + ('/GPU' if args.scaling == 'weak' else ' in total') +
                                    (f', model noise {args.noise}% (256 plant draws) + torque noise {args.control_noise}%' if args.noise > 0 or args.control_noise > 0 else '') +
                                    ', controller ' + CONTROLLER +
                                    (' (soft terminal NN row, ' if CONTROLLER == 'st' else ' (NN row as configured, ') +
@@ -635,8 +652,13 @@ def main():
                        'hip_graphs': bool(subs[0].graph is not None),
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
                        'failed_instance_steps': fails},
+            # host side of the loop: time this rank's Python spent enqueueing one step (all sub-batches) against
+            # the step itself, and the cores it may use -- eight ranks of an 8-GPU run share one host
+            'host_issue_ms_per_step': 1e3 * host_issue / max(args.steps, 1), 'usable_cores': usable_cores(),
             'roofline': roof, 'cpu_baseline': cpu, 'survey_window': survey,
         }
+        if log_check is not None:
+            line['log_check'] = log_check
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + '\n').encode())
     if use_dist:

@@ -34,3 +34,29 @@ def test_bench_runs_as_a_torch_distributed_rank_over_rccl():
     assert d['config']['failed_instance_steps'] == 0 and 3.0 < d['config']['mean_ipm_iterations'] < 12.0
     assert d['roofline']['bound'] == 'hbm' and d['roofline']['achieved'] > 0 and d['cpu_baseline'] is None
     assert d['roofline']['kernel_ms_in_loop']['launches_sampled'] > 0
+    # the host side of the loop, for the day eight ranks share one host
+    assert 0.0 < d['host_issue_ms_per_step'] <= d['ms_per_step'] * 1.05 and d['usable_cores'] >= 1
+    assert d['config']['hip_graphs'] is False
+
+
+@pytest.mark.gpu
+def test_bench_graph_replay_is_legal_under_torch_distributed():
+    """--graphs 1 as a torch.distributed rank: the captured step takes its log slot from a device-side counter, so the rollout
+    log that is gathered holds every step (SMPC_BENCH_CHECK_LOG: bench.py verifies its own log after the timed region)."""
+    import torch
+    from safe_mpc_amd import _lib
+    if torch.cuda.is_initialized() or _lib._lib is not None:
+        pytest.skip('needs a process that has not initialised the GPU (run the whole suite, or this file alone)')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SMPC_FORCE_DIST='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               SMPC_BENCH_CHECK_LOG='1')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '6', '--warmup', '3', '--graphs', '1',
+                        '--no-cpu-baseline', '--no-survey-window'], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d['config']['hip_graphs'] is True and d['steps'] == 6
+    assert d['config']['failed_instance_steps'] == 0 and 3.0 < d['config']['mean_ipm_iterations'] < 12.0
+    assert d['log_check'] == 'ok: 6 distinct log rows, statuses all zero'

@@ -128,3 +128,81 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env2,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ''
+
+
+# ---- C3's partition end to end: strong scaling over a horizon x alpha grid ----------------------------------------
+def _grid_case():
+    """a small horizon x alpha grid in the layout of run_mpc_horizons.sh / run_mpc_alphas.sh: 11 instances (uneven on purpose)"""
+    horizons = np.array([4, 4, 4, 4, 6, 6, 6, 5, 5, 5, 5])
+    alphas = np.array([10.0, 20.0, 30.0, 40.0, 10.0, 20.0, 30.0, 10.0, 20.0, 30.0, 40.0])
+    return horizons, alphas
+
+
+def _solve_group(N, idx, alphas, x0_all):
+    """two closed-loop steps of the instances `idx` (global indices) at horizon N with the CPU test double: [u applied at step 1, status]"""
+    from fake_solver import OracleSolver
+    par, prob, net = make_problem('st', N=int(N))
+    s = OracleSolver(prob, net)
+    x = x0_all[idx]
+    xg, ug, p = constant_guess(prob, x)
+    p[:, :, 3] = alphas[idx][:, None]
+    out = np.zeros((len(idx), prob.nu + 1))
+    for _ in range(2):
+        xg = s.guess_correction(xg, ug)
+        xt, ut, st, it = s.solve(x, xg, ug, p)
+        xg, ug, u = s.provide_control((st == 0).astype(np.int32), xt, ut, xg, ug)
+        x = s.plant_step(x, u)[0]
+        out[:, :prob.nu], out[:, prob.nu] = u, st
+    return out
+
+
+def _worker_grid(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from safe_mpc_amd.sharding import gather_to_root
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    horizons, alphas = _grid_case()
+    par, prob, net = make_problem('st', N=4)
+    x0_all = sample_instances(prob, len(horizons), seed=5)
+    owned = shard_by_horizon(horizons, world, rank)                 # {N: global indices of this rank}
+    rows = []
+    for N, idx in sorted(owned.items()):
+        if len(idx):
+            rows.append(np.hstack([idx[:, None].astype(float), _solve_group(N, idx, alphas, x0_all)]))
+    local = torch.tensor(np.vstack(rows)) if rows else torch.zeros((0, 1 + prob.nu + 1), dtype=torch.float64)
+    got = gather_to_root(local)                                     # ONE gather: [global index | u | status], ragged over ranks
+    if rank == 0:
+        q.put(got.numpy())
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_strong_scaling_grouped_by_horizon_matches_single_process():
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_grid, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = q.get(timeout=180)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    horizons, alphas = _grid_case()
+    # every instance of the grid exactly once, whatever rank and horizon group it went through
+    order = np.argsort(got[:, 0])
+    assert np.array_equal(got[order, 0], np.arange(len(horizons)))
+    # ... and with the result of the unsharded run (instances are independent: bit-identical on the same code path)
+    par, prob, net = make_problem('st', N=4)
+    x0_all = sample_instances(prob, len(horizons), seed=5)
+    for N in np.unique(horizons):
+        idx = np.where(horizons == N)[0]
+        want = _solve_group(N, idx, alphas, x0_all)
+        assert np.array_equal(got[order][idx, 1:], want), N
+    assert (got[:, -1] == 0).all()
