@@ -1016,73 +1016,30 @@ def test_engine_against_independent_dense_qp_solver_at_full_horizon(controller):
         assert np.allclose(xa[b, 30] - xg[b, 30], cq['Phi'][30] @ v + cq['c'][30], atol=1e-6)
 
 
-@pytest.mark.parametrize('controller', ['st', 'constraint_everywhere'])
-def test_late_closed_loop_qps_against_independent_dense_solver(controller):
-    """the solver-independent cross-check on QPs taken from the RUNNING closed loop (steps 40 and 100 of
-    the engine's own loop), not only on cold starts.  Late QPs are soft: the stage Hessian's smallest eigenvalues are LM x dt =
-    2.5e-3, so an exit at mean complementarity 1e-8 (HPIPM's level, config.yaml:15-18) bounds the OBJECTIVE gap (duality
-    gap <= m x 1e-8) but leaves single controls free by up to ~1e-2 along the flat directions -- for this IPM, for the
-    oracle's, and for any other (measured on the oracle: tests/experiments/late_qp_crosscheck.py).
-    Pinned here, for every instance of the batch (the slowest by iteration count included):
+@pytest.mark.parametrize('case', ['st', 'constraint_everywhere', 'receding', 'fr7'])
+def test_late_closed_loop_qps_against_independent_dense_solver(case):
+    """the solver-independent cross-check on QPs taken from the RUNNING closed loop of the engine
+    itself, not only on cold starts -- Z1 'st' and 'constraint_everywhere' (steps 40, 100), 'receding' with its switched running
+    row (the row on at ONE running node that recedes with the step, controller.py:452-469), and BASELINE config 4's 7-DoF / N = 40
+    problem (steps 20, 40).  Late QPs are soft: the stage Hessian's smallest eigenvalues are LM x dt = 2.5e-3, so an exit at mean
+    complementarity 1e-8 (HPIPM's level, config.yaml:15-18) bounds the OBJECTIVE gap (duality gap <= m x 1e-8) but leaves single
+    controls free by up to ~1e-2 along the flat directions -- for this IPM, for the oracle's, and for any other (measured on the
+    oracle: tests/experiments/late_qp_crosscheck.py, DESIGN.md section 5).  Pinned by tests/late_qp.py::run_case for every
+    instance of the batch (the slowest by iteration count included):
       (a) engine == oracle on the same late QP at the RTI tolerance (same algorithm, rounding-different paths);
       (b) the engine's step is feasible for the dense QP and its objective is within the duality-gap bound of the dense optimum;
       (c) the measured gap in the controls at the default exit stays below 5e-2 (the softness, stated);
       (d) with the exit tightened to 1e-12 the engine's step converges to the dense solver's optimum: 2e-3 (1 + |v*|).
     (c) and (d) follow the bound the flat directions allow: an objective gap <= m x tol over a Hessian whose smallest eigenvalue is
     LM x dt = 2.5e-3 leaves |dz| <= sqrt(2 m tol / 2.5e-3): ~0.1 at tol = 1e-8 (m ~ 1300 complementarity pairs), ~1e-3 at 1e-12;
-    measured over the loops of rounds 3-4: 1e-2 and 2e-4 .. 8e-4 -- which instance shows the largest gap changes with rounding-level
+    measured over the loops of rounds 3-5: 1e-2 and 2e-6 .. 8e-4 -- which instance shows the largest gap changes with rounding-level
     changes of the linearisation (the builder of round 4 moved it from 1.8e-4 to 8.1e-4)."""
-    from qp_ref import condense, solve_condensed
-    N, B = 30, 12
-    par, prob, net = make_problem(controller, 'ext', N=N)
-    par_t, prob_t, _ = make_problem(controller, 'ext', N=N, qp_tol=1e-12, qp_tol_res=1e-8)
-    s, s_tight, o = _solver(prob, net), _solver(prob_t, net), _oracle(prob, net)
-    x = sample_instances(prob, B, seed=0)
-    xg, ug, p = constant_guess(prob, x)
-    fails = np.zeros(B, int)
-    worst = {'gap_default': 0.0, 'gap_tight': 0.0, 'obj': 0.0}
-    checked = 0
-    for j in range(101):
-        xg = s.guess_correction(xg, ug)
-        xt, ut, st, it = s.solve(x, xg, ug, p)
-        if j in (40, 100):
-            xo, uo, so, io = o.solve_batch(x, xg, ug, p)
-            xq, uq, sq, iq = s_tight.solve(x, xg, ug, p)
-            assert np.array_equal(st, so) and np.abs(it - io).max() <= 2
-            assert np.abs(ut - uo).max() < 1e-4 * (1 + np.abs(uo).max())                                    # (a)
-            order = np.argsort(-it)                       # slowest first: it is in the set whatever else is
-            for b in order:
-                if st[b] != 0 or sq[b] != 0:
-                    continue
-                cq = condense(o.build_qp(x[b], xg[b], ug[b], p[b]), N, 6, par.dt)
-                v, _, _, nit = solve_condensed(cq)
-                assert nit < 150
-                sw, G, h = cq['soft_w'], cq['G'], cq['h']
-
-                def obj(w):      # quadratic + the L1 penalty of the soft rows' violation (their slack eliminated)
-                    r = G @ w - h
-                    return 0.5 * w @ cq['H'] @ w + cq['g'] @ w + np.sum(np.where(sw >= 0, sw * np.maximum(r, 0.0), 0.0))
-                du = (ut[b] - ug[b]).reshape(-1)
-                dq = (uq[b] - ug[b]).reshape(-1)
-                m = G.shape[0] + int((sw >= 0).sum())
-                # (b) feasible (hard rows; 1e-6: the engine's fp32 network row against the oracle's fp64 restatement in the dense
-                #     QP's data) and within the duality-gap bound m x qp_tol of the optimum (x2 + the same data noise)
-                assert np.max(np.where(sw >= 0, -1.0, G @ du - h)) < 1e-6
-                gap = obj(du) - obj(v)
-                assert -1e-6 * (1 + abs(obj(v))) < gap < 2 * m * 1e-8 + 1e-6 * (1 + abs(obj(v))), (j, b, gap)
-                g0 = np.abs(du - v).max() / (1 + np.abs(v).max())
-                g1 = np.abs(dq - v).max() / (1 + np.abs(v).max())
-                assert g0 < 5e-2, (j, b, g0)                                                                  # (c)
-                assert g1 < 2e-3, (j, b, g1)                                                                  # (d)
-                worst['gap_default'], worst['gap_tight'] = max(worst['gap_default'], g0), max(worst['gap_tight'], g1)
-                worst['obj'] = max(worst['obj'], gap / (1 + abs(obj(v))))
-                checked += 1
-        fails = np.where(st == 0, 0, fails + 1)
-        xg, ug, u = s.provide_control((fails == 0).astype(np.int32), xt, ut, xg, ug)
-        x, _ = s.plant_step(x, u)
-    assert checked >= 16                                  # >= 8 instances at each of the two steps
-    print(f'late QPs [{controller}]: {checked} checked; control gap to the dense optimum at the default exit {worst["gap_default"]:.2e}, '
-          f'at qp_tol 1e-12 {worst["gap_tight"]:.2e}; relative objective gap {worst["obj"]:.2e}')
+    from late_qp import CASES, run_case
+    checked, worst, rows = run_case(case, _solver, _oracle)
+    assert checked >= CASES[case][3] * 2 - 8              # (almost) every instance at each of the two steps
+    print(f'late QPs [{case}]: {checked} checked; control gap to the dense optimum at the default exit {worst["gap_default"]:.2e}, '
+          f'at qp_tol 1e-12 {worst["gap_tight"]:.2e}; relative objective gap {worst["obj"]:.2e}; per step (step, mean it, max it, '
+          f'gap default, gap tight, objective): {[tuple(float(f"{v:.3g}") for v in r) for r in rows]}')
 
 
 def test_engine_against_independent_dense_qp_solver_c4():

@@ -253,3 +253,15 @@ def test_oracle_ipm_on_late_closed_loop_qps_against_the_dense_solver():
         fails = np.where(st == 0, 0, fails + 1)
         xg, ug, u = o.provide_control((fails == 0).astype(np.int32), xt, ut, xg, ug)
         x, _ = o.plant_step(x, u)
+
+
+@pytest.mark.parametrize('case', ['receding', 'fr7'])
+def test_oracle_ipm_on_late_closed_loop_qps_receding_and_7dof(case):
+    """The same (tests/late_qp.py) for what the round-4 cross-check did not cover: 'receding' with its switched
+    running row, and the 7-DoF / N = 40 problem of BASELINE config 4, on QPs of a running closed loop of the oracle.  Measured
+    (DESIGN.md section 5): control gap at the default exit 8e-3 / 9e-3, at qp_tol = 1e-12 2e-5 / 2e-6, objective gap 6e-6 / 3e-6."""
+    from fake_solver import OracleSolver
+    from late_qp import run_case
+    checked, worst, rows = run_case(case, lambda prob, net: OracleSolver(prob, net), lambda prob, net: Oracle(prob, (net.weights, net.biases)),
+                                    steps=(40,) if case == 'receding' else (20,), B=3, same_as_oracle=False, feas_tol=1e-9)
+    assert checked == 3 and worst['gap_tight'] < 2e-4 and worst['obj'] < 2e-5
