@@ -251,7 +251,8 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
     {
         const long rows_all = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128 : (long)Mp;
         static const bool no_fused = getenv("SMPC_MLP_UNFUSED") != nullptr;     // (A/B knob)
-        if (!no_fused && rows_all < 8192 && H == MLPF_H && L == 4 && (!backward || (d_p && d_ev))) {
+        static const long fused_max = [] { const char* e = getenv("SMPC_MLP_FUSED_MAX"); return e ? atol(e) : 8192L; }();   // (A/B knob)
+        if (!no_fused && rows_all < fused_max && H == MLPF_H && L == 4 && (!backward || (d_p && d_ev))) {
             MlpWeights Wt;
             for (int l = 0; l < SMPC_MAX_LAYERS; l++) { Wt.wf[l] = h->d_Wfwd[l]; Wt.wb[l] = h->d_Wbwd[l]; Wt.bias[l] = h->d_bias[l]; }
             const dim3 grd((M + MLPF_ROWS - 1) / MLPF_ROWS), blk(256);
@@ -1391,8 +1392,8 @@ int smpc_get_qp_wave_stats(smpc_handle* h, double* out3) {
 
 // Test hook (not part of include/smpc.h): the stage records of the QP workspace as either path builds them (path 1: MLP ->
 // k_stage_build; path 0: k_node_linearise -> MLP -> k_qp_setup), copied to the host, and the layout's offsets -- so that
-// tests/test_gpu_parity.py can compare the two builders block by block.  Host pointers.  layout[16] = {stride, nIMG, oIMG, oSL,
-// oAUX, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, doubles per instance, 0}.
+// tests/test_gpu_parity.py can compare the two builders block by block.  Host pointers.  layout[24] = {stride, nIMG, oIMG, oSL,
+// nF, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, doubles per instance, record version, iTT, iGT, iGN, iB, iSC, iHQQ, iGZ, 0}.
 extern "C" int smpc_debug_stage_records(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
                                         int path, double* ws_out, int32_t* layout) {
     if (!h || B <= 0 || !x0 || !xg || !ug || !p || !ws_out || !layout) return SMPC_EINVAL;
@@ -1412,9 +1413,9 @@ extern "C" int smpc_debug_stage_records(smpc_handle* h, int B, const double* x0,
     HIPCHK(h, hipMemcpyAsync(ws_out, h->d_ws, per * (size_t)B * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     auto fill = [&](auto Ly) {
-        const int v[16] = {Ly.stride, Ly.nIMG, Ly.oIMG, Ly.oSL, Ly.oAUX, Ly.oR0, Ly.oR1, Ly.oR2, Ly.oCZA, Ly.oCZN, Ly.oZ, Ly.oZN, Ly.NRT, Ly.nJ,
-                           (int)per, 0};
-        for (int i = 0; i < 16; i++) layout[i] = v[i];
+        const int v[24] = {Ly.stride, Ly.nIMG, Ly.oIMG, Ly.oSL, Ly.nF, Ly.oR0, Ly.oR1, Ly.oR2, Ly.oCZA, Ly.oCZN, Ly.oZ, Ly.oZN, Ly.NRT, Ly.nJ,
+                           (int)per, 12, Ly.iTT, Ly.iGT, Ly.iGN, Ly.iB, Ly.iSC, Ly.iHQQ, Ly.iGZ, 0};
+        for (int i = 0; i < 24; i++) layout[i] = v[i];
     };
     switch (h->desc.nq) {
     case 5: fill(QpLayout<5>(h->desc.n_rows)); break;

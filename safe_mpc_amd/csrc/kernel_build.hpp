@@ -484,8 +484,6 @@ __device__ __forceinline__ void stage_build(const smpc_problem_desc* __restrict_
     }
     bmax = grp_max(bmax);
     const double bflag = bmax > 0.0 ? 1.0 : 0.0;
-    for (int i = g; i < NX; i += SB_G)
-        if (valid) stnt_su(dbl2{defect(i), wsoft}, reinterpret_cast<dbl2*>(w + Ly.oAUX) + i);
     // cost gradient: u part R u, q part from the EE point (owned by the joint lanes), v part 0
     auto gz_u = [&](int c) -> double { return (reach && !last) ? cs * 2.0 * D->R * uk[c] : 0.0; };
     for (int hz = g; hz < NZP; hz += SB_G) {

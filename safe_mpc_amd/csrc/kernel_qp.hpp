@@ -80,9 +80,10 @@ template <int NQ> struct QpLayout {
     int MR, MRP, NRC, NRT;
     // image of the factorisation sweep (copied verbatim into LDS), offsets relative to oIMG
     int iTT, iGT, iGN, iHQQ, iGZ, iB, iSC, nIMG;
-    int nJ;                                                     // doubles of the image's Jacobian part [Tt | Gt | gn] (the forward sweeps fetch only this)
-    int oIMG, oW, oSL, oPART, oWC, oAUX, oR0, oR1, oR2, oCZA, oCZN;
-    int oZ, oZN, oGH0, oA12;
+    int nJ;                                                     // doubles of the image's Jacobian part [Tt | Gt | gn]
+    int nF;                                                     // ... and of what the forward sweeps fetch: [Tt | Gt | gn | b | scalars]
+    int oIMG, oW, oSL, oPART, oWC, oR0, oR1, oR2, oCZA, oCZN;
+    int oZ, oZN, oA12;
     int stride;
     __host__ __device__ explicit QpLayout(int n_rows) {
         MR = n_rows;
@@ -94,10 +95,14 @@ template <int NQ> struct QpLayout {
         iGT = i; i += NQ * MRP;            // collision rows transposed (q columns): Gt[ix][r]
         iGN = i; i += NX;                  // safe-set row
         nJ = i;                            // (even: NQP, MRP are, and NX = 2 NQ)
-        iHQQ = i; i += qp_even_c(NQ * NQ); // cost Hessian (q block) + LM
-        iGZ = i; i += NZP;                 // cost gradient
+        // (v12: the defect and the stage scalars sit right behind the Jacobian, so that the forward sweeps get them with the pieces
+        //  they fetch anyway -- the same number of load instructions -- instead of from a block of (b_i, soft weight) pairs of their
+        //  own: 24 doubles per stage and forward sweep, one load instruction per stage, and the set-up's store of that block)
         iB = i; i += NX;                   // dynamics defect
         iSC = i; i += 4;                   // [Huu diagonal, LM on the v diagonal, soft weight, b != 0]
+        nF = i;                            // (even)
+        iHQQ = i; i += qp_even_c(NQ * NQ); // cost Hessian (q block) + LM
+        iGZ = i; i += NZP;                 // cost gradient
         nIMG = i;                          // (even)
         int o = 0;
         // (v11: the constraint Jacobian is stored ONCE, in the image's transposed layout; v1-v10 kept a second, row-major copy
@@ -108,7 +113,6 @@ template <int NQ> struct QpLayout {
         oSL = o; o += 16;                  // [soft weight, b != 0, ., . | setup partials: R0, sum lambda t, count, node-0 rows
         oPART = oSL + 4;                   //  infeasible | the corrector's w (B2 -> F2; one whole 64-byte sector)]
         oWC = oSL + 8;
-        oAUX = o; o += qp_al8(2 * NX);     // per state lane, as pairs: [b_i, soft weight]  (one load in the forward sweeps)
         oR0 = o; o += qp_al8(NRT * 2);     // per row, as arrays of pairs: [lo, hi]
         oR1 = o; o += qp_al8(NRT * 2);     //   [t_l, t_u]        (the soft row has no upper side: its slack lives in t_u)
         oR2 = o; o += qp_al8(NRT * 2);     //   [lambda_l, lambda_u]
@@ -116,8 +120,11 @@ template <int NQ> struct QpLayout {
         oCZN = o; o += 32;                 //   (as the two halves of a pair, each sweep's store was a read-modify-write of every sector)
         oZ = o; o += qp_al8(NZ);
         oZN = o; o += qp_al8(NZ);
-        oGH0 = o; o += qp_al8(NZ);         // predictor gradient g + C^T e0 with P b folded in: + [B^T P b; A^T P b] (B1 -> B2)
-        oA12 = o; o += qp_al8(2 * NZ);     // pairs (C^T e1, C^T e2): the corrector gradient is gh0 + sigma mu a1 + cw a2 (F1 -> B2)
+        // (v12: no stored predictor gradient.  The corrector's costate recursion is linear in its gradient gh0 + sigma mu a1 + cw a2,
+        //  and the part that belongs to gh0 is the predictor costate B1 has already computed -- its w is a column of the factor block.
+        //  B2 propagates the DIFFERENCE, driven by sigma mu a1 + cw a2 alone, and F2 adds the two w: 18 doubles fewer written by B1
+        //  and read by B2 per stage, no P b folded into anything.)
+        oA12 = o; o += qp_al8(2 * NZ);     // pairs (C^T e1, C^T e2): the corrector's costate increment is driven by sigma mu a1 + cw a2 (F1 -> B2)
         static_assert(NQ <= 8, "the corrector's w shares a 16-double block with the stage scalars");
         stride = (o + 15) & ~15;
     }
@@ -540,7 +547,6 @@ __global__ __launch_bounds__(32 * EV_TILE) void k_qp_setup(const smpc_problem_de
     }
     if (hl < 4) stnt_su(hl == 0 ? wsoft : (hl == 1 ? bflag : 0.0), w + Ly.oSL + hl);
     if (hl < 8) stnt_su(0.0, w + Ly.oWC + hl);
-    if (hl < NX) stnt_su(dbl2{sB[hl], wsoft}, reinterpret_cast<dbl2*>(w + Ly.oAUX) + hl);
     if (hl < NZ) { stnt_su(sZ0[hl], w + Ly.oZ + hl); stnt_su(sZ0[hl], w + Ly.oZN + hl); }
     lds_fence();
     // stationarity residual at the initial point (pi = 0): g - C^T (ll - lu); dx_0 does not enter (no cost cross term)
@@ -613,7 +619,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
     constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
     constexpr int CST_MAX = NRC_MAX * NZP;                                       // row-major image of the general rows in LDS
-    constexpr int NJ_MAX = NZ * NQP + NQ * MRP_MAX + NX, CST_PF = (NJ_MAX / 2 + 31) / 32;   // ... fetched as the image's [Tt | Gt | gn]
+    constexpr int NF_MAX = NZ * NQP + NQ * MRP_MAX + NX + NX + 4, CST_PF = (NF_MAX / 2 + 31) / 32;   // ... fetched as the image's [Tt | Gt | gn | b | scalars]
     constexpr int W_N2 = NWP / 2, WST_PF = (W_N2 + 31) / 32;                 // ... and the factor block
     // (staged in LDS by the other sweeps, in the buffers that only the factorisation sweep uses)
 #ifdef QP_PROFILE
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const ws = ws_all + (size_t)b * Ly.per_instance(N);
     const double dt = D->dt, cB = 0.5 * dt * dt;
     const int img_n2 = Ly.nIMG >> 1;   // 16-byte pieces of the image
-    const int c_n2 = Ly.nJ >> 1;            // ... and of its Jacobian part (what the forward sweeps fetch)
+    const int c_n2 = Ly.nF >> 1;            // ... and of its part [Tt | Gt | gn | b | scalars] (what the forward sweeps fetch)
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
     // [image | D | E | -- buffers of the factorisation sweep only: TD GD Lambda G Wt Hxx P P -- | vectors]
@@ -1021,11 +1027,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         for (int r = 0; r < MR; r++) cq = fma(sGT[iq * MRP + r], sE[rC0 + r], cq);
                     }
                     const double gh = g0 + tq + (hz >= NU ? eb + gnn + (ix < NQ ? cq : 0.0) : 0.0);
-                    // the corrector gradient is affine in (sigma mu, cw): B2 starts from this one.  Its recursion needs P b only as
-                    // B^T P b (controls) and A^T P b (states), both constants of the iteration: stored with the gradient, so B2
-                    // loads no P b (sPB of this stage was written before the last fence; it is zero at the end stage)
-                    const double fold = (ctl ? cB : 1.0) * pb1 + (ctl || ix >= NQ ? dt : 0.0) * pb2;
-                    stnt_s(last ? gh : gh + fold, w + Ly.oGH0 + hz);
+                    // (nothing of this gradient is stored: the corrector's backward sweep only propagates what sigma mu a1 + cw a2 add
+                    //  to this recursion, see the layout)
                     if (last) {
                         if (hz >= NU) pvn[hz - NU] = gh;
                     } else {
@@ -1178,7 +1181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
             // issued after stage k's rows had been consumed, ~0.6 of a stage ahead -- under full load less than the memory
             // latency, and the row phase of every forward stage stalled for the difference: 1.0 M of the 5.2 M clocks of a
             // half-wave, profiles/r02_qp_phase_profile.txt.)
-            struct RSet { dbl2 r0, r1, r2; double cza, wc, bi, wsoft; };
+            struct RSet { dbl2 r0, r1, r2; double cza, wc; };
             RSet RA, RB;
             // Where the two entries of piece j of this lane go in the row-major LDS image (offsets in doubles from sIMG): the pieces
             // come in the image's transposed layout -- Tt[c][r], Gt[ix][r], gn[i] -- and are transposed on their way into LDS (two
@@ -1196,7 +1199,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                         const int t = e - NZ * NQP, ix = t / max(MRP, 1), r = t - ix * MRP;
                         return r < MR ? O_TD + (NQ + r) * NZP + NU + ix : 0;
                     }
-                    return O_TD + (NQ + MR) * NZP + NU + (e - NZ * NQP - NQ * MRP);
+                if (e < Ly.nJ) return O_TD + (NQ + MR) * NZP + NU + (e - NZ * NQP - NQ * MRP);
+                return e;                  // the defect and the stage scalars: their own cells of the (idle) image area -- sB, sSC
                 };
 #pragma unroll
                 for (int j = 0; j < CST_PF; j++) {
@@ -1236,9 +1240,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     R.cza = ldnt_s(w + Ly.oCZA + hr);
                     R.wc = ldnt_s(w + Ly.oWC + hl_u);   // the corrector's w (B2)
                 }
-                const dbl2 aux = ldnt_s(reinterpret_cast<const dbl2*>(w + Ly.oAUX) + hl_x);
-                R.bi = aux.x;
-                R.wsoft = aux.y;
             };
             if (hl < NX) sIMG[o_xb + hl] = dx0_reg;
             load_w(0);
@@ -1273,7 +1274,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 {
                     const double* wr_ = wc_ + hl_u;          // row hl_u of [W | w]: one entry per column
                     // (q and v halves in accumulators of their own: this chain is on the path from one stage's state to the next)
-                    double a = CORR ? cur.wc : wr_[NX * NQ], a_v = 0.0;
+                    double a = wr_[NX * NQ] + (CORR ? cur.wc : 0.0), a_v = 0.0;   // (the predictor's w + the corrector's increment, B2)
 #pragma unroll
                     for (int j = 0; j < NQ; j++) {
                         a = fma(wr_[j * NQ], xb[j], a);
@@ -1295,7 +1296,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 if (!last && hl < NX) {
                     const int i = hl < NQ ? hl : hl - NQ;
                     const double u = sZU[i];
-                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + cur.bi : xb[hl] + dt * u + cur.bi;
+                    const double bi = sB[hl];      // (this stage's defect: it came in with the Jacobian pieces)
+                    xn[hl] = hl < NQ ? xb[hl] + dt * xb[NQ + hl] + cB * u + bi : xb[hl] + dt * u + bi;
                 }
                 // rows: c.z for the trial point, directions, ratio test
                 {
@@ -1310,7 +1312,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     a += a_q + a_v;
                     const double cz = hr < NX ? xb[hl_x] : a;
                     const QpRow rs{cur.r0.x, cur.r0.y, cur.r1.x, cur.r1.y, cur.r2.x, cur.r2.y};
-                    const double wsoft = cur.wsoft;
+                    const double wsoft = sSC[2];
                     const bool soft = soft_lane && wsoft >= 0.0;
                     double s1_ = 0.0, s2_ = 0.0;
                     if (!CORR) {
@@ -1397,13 +1399,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #define QP_B2_DEPTH 5
 #endif
             constexpr int B2D = QP_B2_DEPTH;
-            struct BSet { double gh0; dbl2 a12; dbl2 Ws[WST_PF]; };
+            struct BSet { dbl2 a12; dbl2 Ws[WST_PF]; };
             // the two entries of P b this lane needs: controls (i, NQ+i), states (ix, ix-NQ)
             const int ip1 = hl < NU ? hl : hl_px;
             const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
             auto load_b = [&](BSet& S, int k) {
                 const double* w = stage_ptr(k);
-                S.gh0 = ldnt_s(w + Ly.oGH0 + hz);
                 S.a12 = ldnt(reinterpret_cast<const dbl2*>(w + Ly.oA12) + hz);
                 const int kf = k < N ? k : N - 1;   // (there are no factors at the end stage)
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(stage_ptr(kf) + Ly.oW);
@@ -1415,7 +1416,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 asm volatile("; QPMARK B2_BEGIN");
                 double* w = stage_ptr(k);
                 const int kp = k > B2D ? k - B2D : 0;
-                const double gh = S.gh0 + sigmu * S.a12.x + corr_w * S.a12.y;   // (P b is inside gh0: B1)
+                const double gh = sigmu * S.a12.x + corr_w * S.a12.y;   // (the increment's gradient: the predictor's part is in B1's w)
                 if (last) {
                     if (hz >= NU) pvn[hz - NU] = gh;
                     // (the factor pieces of this set are never used: consume them so that their registers stay reserved)

@@ -6,14 +6,28 @@ import numpy as np, torch
 import bench
 from safe_mpc_amd.solver import BatchedOcpSolver
 
-par, prob, net = bench.build_problem()
+# SMPC_QPB_PROBLEM=fr7: BASELINE config 4's problem (7-DoF, N = 40, row on every node) at one sub-batch launch of scripts/c4_bench.py
+FR7 = os.environ.get('SMPC_QPB_PROBLEM') == 'fr7'
+if FR7:
+    from safe_mpc_amd.parser import Parameters
+    from safe_mpc_amd.problem import OcpProblem
+    from safe_mpc_amd.safe_set import SafeSetNet
+    par = Parameters({}, 'fr7', filename=os.path.join(ROOT, 'config_fr7.yaml'))
+    par.N = 40
+    prob = OcpProblem(par, 'constraint_everywhere', 'ext', N=40)
+    net = SafeSetNet.from_params(par, prob.x_min, prob.x_max)
+    prob.set_normalisation(net.mean, net.std)
+else:
+    par, prob, net = bench.build_problem()
 if os.environ.get('SMPC_MAXIT'):
     prob.desc.qp_max_iter = int(os.environ['SMPC_MAXIT'])
 s = BatchedOcpSolver(prob, net)
-B = int(os.environ.get('SMPC_B', '4096'))
+B = int(os.environ.get('SMPC_B', '5461' if FR7 else '4096'))
 x0 = bench.initial_states(s, prob, B, 0)
+if FR7:
+    x0[:, prob.nq:] = 0.1 * np.random.default_rng(0).uniform(-1, 1, (B, prob.nq)) * prob.ubx[prob.nq:]      # (as scripts/c4_bench.py)
 N = prob.N
-xg = np.repeat(x0[:, None, :], N + 1, axis=1); ug = np.zeros((B, N, 6)); p = np.zeros((B, N + 1, 5))
+xg = np.repeat(x0[:, None, :], N + 1, axis=1); ug = np.zeros((B, N, prob.nq)); p = np.zeros((B, N + 1, 5))
 p[:, :, :3], p[:, :, 3], p[:, :, 4] = prob.ee_ref, par.alpha, 1.0
 x = x0
 for i in range(int(os.environ.get('SMPC_WARM', '5'))):

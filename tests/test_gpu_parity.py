@@ -291,7 +291,7 @@ def _stage_records(s, x0, xg, ug, p, path):
     import ctypes as C
     L = s.L
     L.smpc_debug_stage_records.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p]
-    lay = np.zeros(16, np.int32)
+    lay = np.zeros(24, np.int32)
     B = x0.shape[0]
     # (first call with a one-element buffer only to learn the size)
     arrs = [np.ascontiguousarray(a, np.float64) for a in (x0, xg, ug, p)]
@@ -372,10 +372,10 @@ def test_stage_builder_equals_thread_per_node_kernels(case):
     new, lay = _stage_records(s, x0, xg, ug, p, 1)
     old, lay2 = _stage_records(s, x0, xg, ug, p, 0)
     assert np.array_equal(lay, lay2)
-    stride, nIMG, oIMG, oSL, oAUX, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, per = [int(v) for v in lay[:15]]
+    stride, nIMG, oIMG, oSL, nF, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, per = [int(v) for v in lay[:15]]
     new, old = new.reshape(B, N + 1, stride), old.reshape(B, N + 1, stride)
-    blocks = {'jacobian': (oIMG, nJ), 'cost / defect / scalars': (oIMG + nJ, nIMG - nJ), 'scalars + partial sums + w': (oSL, 16),
-              'aux': (oAUX, 2 * prob.nx), 'bounds': (oR0, 2 * NRT), 'slacks': (oR1, 2 * NRT), 'multipliers': (oR2, 2 * NRT),
+    blocks = {'jacobian': (oIMG, nJ), 'defect / scalars': (oIMG + nJ, nF - nJ), 'cost': (oIMG + nF, nIMG - nF),
+              'scalars + partial sums + w': (oSL, 16), 'bounds': (oR0, 2 * NRT), 'slacks': (oR1, 2 * NRT), 'multipliers': (oR2, 2 * NRT),
               'c.z_aff': (oCZA, 32), 'c.z+': (oCZN, 32), 'z': (oZ, 3 * prob.nq), 'z+': (oZN, 3 * prob.nq)}
     for name, (o, n) in blocks.items():
         a, b = new[:, :, o:o + n], old[:, :, o:o + n]
@@ -413,15 +413,13 @@ def test_stage_builder_records_equal_oracle_qp(case):
     xg[:, 1:] += 0.01 * rng.standard_normal(xg[:, 1:].shape)
     x0 = x0 + 0.003 * rng.standard_normal(x0.shape)
     ws, lay = _stage_records(s, x0, xg, ug, p, 1)
-    stride, nIMG, oIMG, oSL, oAUX, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, per = [int(v) for v in lay[:15]]
+    stride, nIMG, oIMG, oSL, nF, oR0, oR1, oR2, oCZA, oCZN, oZ, oZN, NRT, nJ, per = [int(v) for v in lay[:15]]
     ws = ws.reshape(B, N + 1, stride)
     MR = prob.desc.n_rows
     NQP, MRP, NZ = nq + nq % 2, MR + MR % 2, 3 * nq
-    iTT, iGT, iGN = 0, NZ * NQP, NZ * NQP + nq * MRP
-    iHQQ = iGN + nx
-    iGZ = iHQQ + nq * nq + (nq * nq) % 2
-    iB = iGZ + NZ + NZ % 2
-    assert iB + nx + 4 == nIMG and iHQQ == nJ
+    iTT, iGT, iGN, iB, iSC, iHQQ, iGZ = [int(v) for v in lay[16:23]]        # (record v12: the hook reports the image's own offsets)
+    assert (iTT, iGT, iGN) == (0, NZ * NQP, NZ * NQP + nq * MRP) and iGN + nx == nJ and int(lay[15]) == 12
+    assert sorted([iB, iSC, iHQQ, iGZ])[0] == nJ and max(iB + nx, iSC + 4, iHQQ + nq * nq, iGZ + NZ) <= nIMG
 
     def close(a, b, tol, what):
         scale = np.abs(b).max() + 1e-300
@@ -450,7 +448,7 @@ def test_stage_builder_records_equal_oracle_qp(case):
             assert np.all(gz[nu + nq:] == 0.0)
             close(img[iB:iB + nx], qp['b'][k][:nx], 1e-9, 'defect')
             if not last:
-                assert abs(img[iB + nx] - H[0, 0]) <= 1e-12 * abs(H[0, 0])          # Huu diagonal
+                assert abs(img[iSC] - H[0, 0]) <= 1e-12 * abs(H[0, 0])              # Huu diagonal
             r0 = ws[b, k, oR0:oR0 + 2 * NRT].reshape(NRT, 2)
             nr = int(qp['nr'][k])
             assert nr == NRT
