@@ -1398,7 +1398,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #ifndef QP_B2_DEPTH
 #define QP_B2_DEPTH 5
 #endif
-            constexpr int B2D = QP_B2_DEPTH;
+            // (NQ = 7: a register set is 16 registers -- three pieces of the factor block instead of two -- and five of them pushed the
+            //  kernel into spill reloads inside every stage of this sweep; three sets, as rounds 1-3 had for every size)
+            constexpr int B2D = NQ >= 7 ? 3 : QP_B2_DEPTH;
             struct BSet { dbl2 a12; dbl2 Ws[WST_PF]; };
             // the two entries of P b this lane needs: controls (i, NQ+i), states (ix, ix-NQ)
             const int ip1 = hl < NU ? hl : hl_px;
