@@ -484,36 +484,6 @@ struct Stage {
     double z[MAXZ], zn[MAXZ];
 };
 
-/* EXPERIMENT knobs (tests/experiments/ipm_variants.py; env SMPC_ORACLE_X_*), all off by default */
-struct QpExp {
-    int no2nd = 0;          /* 1: no second-order term (the "two right-hand sides" iteration) */
-    int affexit = 0;        /* 1: take the affine step and stop when it meets the exit test */
-    double skip_a = 2.0;    /* skip the corrector when a_aff >= skip_a and mu_aff / mu <= skip_r */
-    double skip_r = 0.0;
-    int gondzio = 0;        /* extra centrality correctors */
-    double ftb = 0.995;
-    double sig_cap = 0.3;
-    double sig_pow = 3.0;
-    int cw_mode = 0;        /* 1: corr_w = a_aff^2 always; 2: corr_w = a_aff always */
-    double ftb_hi = 0.9999; /* cap of the adaptive fraction to the boundary */
-    double ftb_gate = 0.99;
-};
-static QpExp g_x;
-static void read_exp() {
-    auto gd = [](const char* k, double d) { const char* v = std::getenv(k); return v ? atof(v) : d; };
-    g_x.no2nd = (int)gd("SMPC_ORACLE_X_NO2ND", 0);
-    g_x.affexit = (int)gd("SMPC_ORACLE_X_AFFEXIT", 0);
-    g_x.skip_a = gd("SMPC_ORACLE_X_SKIP_A", 2.0);
-    g_x.skip_r = gd("SMPC_ORACLE_X_SKIP_R", 0.0);
-    g_x.gondzio = (int)gd("SMPC_ORACLE_X_GONDZIO", 0);
-    g_x.ftb = gd("SMPC_ORACLE_X_FTB", 0.995);
-    g_x.sig_cap = gd("SMPC_ORACLE_X_SIGCAP", 0.3);
-    g_x.sig_pow = gd("SMPC_ORACLE_X_SIGPOW", 3.0);
-    g_x.cw_mode = (int)gd("SMPC_ORACLE_X_CWMODE", 0);
-    g_x.ftb_hi = gd("SMPC_ORACLE_X_FTBHI", 0.9999);
-    g_x.ftb_gate = gd("SMPC_ORACLE_X_FTBGATE", 0.99);
-}
-
 struct QpOpts {
     int max_iter;
     double tol, tol_res, mu0;   /* complementarity / linear-residual exit tolerances */
@@ -525,8 +495,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
            double* res_out) {
     const int nq = nu;
     const double c = 0.5 * dt * dt;
-    const double thr_hard = 3e-2, thr_soft = 1e-1, tau_ftb = g_x.ftb, alpha_min = 1e-12;
-    int n_skipped = 0;
+    const double thr_hard = 3e-2, thr_soft = 1e-1, tau_ftb = 0.995, alpha_min = 1e-12;
 
     /* A x, A^T x, B u, B^T x for the double integrator (env_model.py:63-67) */
     auto Ax = [&](const double* x, double* y) {
@@ -839,48 +808,29 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         if (!factorize()) { status = 4; break; }
         /* predictor */
         solve(0.0, false);
-        const double a_raw = max_step();
-        double a_aff = std::min(1.0, a_raw);
-        auto comp_at = [&](double a) {
-            double acc = 0.0;
-            for (int k = 0; k <= N; k++) {
-                Stage& s = S[k];
-                for (int r = 0; r < s.nr; r++) {
-                    if (s.has_lo[r]) {
-                        acc += (s.ll[r] + a * s.dll[r]) * (s.tl[r] + a * s.dtl[r]);
-                        if (s.soft[r] >= 0.0)
-                            acc += (s.soft[r] - s.ll[r] - a * s.dll[r]) * (s.sl[r] + a * s.dsl[r]);
-                    }
-                    if (s.has_hi[r]) acc += (s.lu[r] + a * s.dlu[r]) * (s.tu[r] + a * s.dtu[r]);
+        double a_aff = std::min(1.0, max_step());
+        double acc = 0.0;
+        for (int k = 0; k <= N; k++) {
+            Stage& s = S[k];
+            for (int r = 0; r < s.nr; r++) {
+                if (s.has_lo[r]) {
+                    acc += (s.ll[r] + a_aff * s.dll[r]) * (s.tl[r] + a_aff * s.dtl[r]);
+                    if (s.soft[r] >= 0.0)
+                        acc += (s.soft[r] - s.ll[r] - a_aff * s.dll[r]) * (s.sl[r] + a_aff * s.dsl[r]);
                 }
+                if (s.has_hi[r]) acc += (s.lu[r] + a_aff * s.dlu[r]) * (s.tu[r] + a_aff * s.dtu[r]);
             }
-            return acc / m_comp;
-        };
-        double mu_aff = comp_at(a_aff);
+        }
+        double mu_aff = acc / m_comp;
         double sigma = mu_aff / mu;
-        sigma = std::pow(sigma, g_x.sig_pow);
+        sigma = sigma * sigma * sigma;
         /* safeguard against Mehrotra cycling: the second-order term models a FULL affine step; when the affine step is
          * blocked early (a_aff < 0.3) it is scaled by a_aff^2, which turns the iteration into a centring step */
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
-        if (g_x.no2nd) corr_w = 0.0;
-        if (g_x.cw_mode == 1) corr_w = a_aff * a_aff;
-        if (g_x.cw_mode == 2) corr_w = a_aff;
         /* centring cap: Mehrotra's (mu_aff/mu)^3 asks for an almost pure centring step (sigma ~ 0.8-1) whenever the affine
          * step is blocked early; those steps stall on nearly-active rows.  Capping sigma at 0.3 keeps the mean iteration
          * count and halves the tail (max 21 -> 11 on the closed-loop 'st' workload) */
-        sigma = std::min(sigma, g_x.sig_cap);
-        bool skip = false;
-        double alpha;
-        {
-            const double tau_p = a_raw >= 0.99 ? std::min(0.9999, std::max(tau_ftb, 1.0 - mu)) : tau_ftb;
-            const double alpha_p = std::min(1.0, tau_p * a_raw);
-            const double mu_p = comp_at(alpha_p);
-            if (g_x.affexit && mu_p <= o.tol && rho * (1.0 - alpha_p) * R0 <= o.tol_res) skip = true;
-            if (a_aff >= g_x.skip_a && mu_aff <= g_x.skip_r * mu) skip = true;
-            alpha = alpha_p;
-        }
-        if (skip) n_skipped++;
-        else {
+        sigma = std::min(sigma, 0.3);
         /* corrector */
         solve(sigma * mu, true);
         /* fraction to the boundary: 0.995 far from the solution, approaching 1 with the complementarity (capped at
@@ -888,9 +838,8 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
          * that is blocked earlier keeps the classical 0.5% margin, otherwise the blocking pair lands far off-centre and
          * the next iterations cycle.  Saves the last 0.005-per-iteration crawl. */
         const double a_max = max_step();
-        const double tau_k = a_max >= g_x.ftb_gate ? std::min(g_x.ftb_hi, std::max(tau_ftb, 1.0 - mu)) : tau_ftb;
-        alpha = std::min(1.0, tau_k * a_max);
-        }
+        const double tau_k = a_max >= 0.99 ? std::min(0.9999, std::max(tau_ftb, 1.0 - mu)) : tau_ftb;
+        double alpha = std::min(1.0, tau_k * a_max);
         if (!(alpha == alpha)) { status = 4; break; }
         if (alpha < alpha_min) { status = 3; break; }
         for (int k = 0; k <= N; k++) {
@@ -919,16 +868,8 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         if (!(mu == mu)) { status = 4; break; }
     }
     if (it == o.max_iter && status == 2 && mu <= o.tol && rho * R0 <= o.tol_res) status = 0;
-    *iters = it + 1000 * n_skipped;
+    *iters = it;
     if (res_out) { res_out[0] = mu; res_out[1] = rho * R0; }
-    if (res_out && std::getenv("SMPC_ORACLE_X_COUNT_ACTIVE")) {
-        int na = 0;
-        for (int k = 0; k <= N; k++) for (int r = 0; r < S[k].nr; r++) {
-            if (S[k].has_lo[r] && S[k].ll[r] > S[k].tl[r]) na++;
-            if (S[k].has_hi[r] && S[k].lu[r] > S[k].tu[r]) na++;
-        }
-        res_out[1] = na;
-    }
     return status;
 }
 
@@ -1189,7 +1130,6 @@ int orc_solve_batch(void* h, int B, const double* x0, const double* xg, const do
     Oracle* o = (Oracle*)h;
     const smpc_problem_desc& D = o->D;
     int N = o->N, nq = D.nq, nx = 2 * nq, nu = nq;
-    read_exp();
     QpOpts qo{D.qp_max_iter, D.qp_tol, D.qp_tol_res > 0.0 ? D.qp_tol_res : D.qp_tol, D.qp_mu0, D.qp_stall_iters};
 #pragma omp parallel for schedule(dynamic, 1)
     for (int b = 0; b < B; b++) {
