@@ -266,6 +266,24 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
             if (chained) *chained = backward;
             return SMPC_OK;
         }
+        // Many rows (the row on every node): the same pass as ONE-WAVE blocks (k_mlp_wave, round 5) -- a block fits where a single QP
+        // wavefront has retired, and only the activation derivatives leave the chip.  SMPC_MLP_LARGE=chain brings the layer-by-layer
+        // GEMMs back (A/B runs; they also serve any network that is not 256 wide with three hidden layers).
+        static const bool large_chain = [] { const char* e = getenv("SMPC_MLP_LARGE"); return e && !strcmp(e, "chain"); }();
+        if (!no_fused && !large_chain && rows_all >= fused_max && H == MLPF_H && L == 4 && (!backward || (d_p && d_ev))) {
+            MlpWeights Wt;
+            for (int l = 0; l < SMPC_MAX_LAYERS; l++) { Wt.wf[l] = h->d_Wfwd[l]; Wt.wb[l] = h->d_Wbwd[l]; Wt.bias[l] = h->d_bias[l]; }
+            const dim3 grd((M + MLPF_ROWS - 1) / MLPF_ROWS), blk(64);
+            if (backward)
+                hipLaunchKernelGGL((k_mlp_wave<NQ, true>), grd, blk, 0, s, h->d_desc, M, N, mode, h->act, Wt, d_x, d_p, idx, live, h->d_y, d_ev,
+                                   compact, h->d_dg[0], h->d_dg[1], h->d_dg[2]);
+            else
+                hipLaunchKernelGGL((k_mlp_wave<NQ, false>), grd, blk, 0, s, h->d_desc, M, N, mode, h->act, Wt, d_x, d_p, idx, live, h->d_y,
+                                   (double*)nullptr, 0, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+            HIPCHK(h, hipGetLastError());
+            if (chained) *chained = backward;
+            return SMPC_OK;
+        }
     }
     hipLaunchKernelGGL((k_nn_features<NQ>), dim3((Mp + 63) / 64), dim3(64), 0, s, h->d_desc, M, Mp, N, mode, d_x,
                        h->d_S, idx, live);

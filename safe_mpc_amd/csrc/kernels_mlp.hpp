@@ -553,4 +553,247 @@ __global__ __launch_bounds__(256) void k_mlp_fused(const smpc_problem_desc* __re
     }
 }
 
+// =========================================================================================================================
+// k_mlp_wave: the whole network pass as ONE-WAVE blocks, for LARGE row counts (the safe-set row on every node: M = B * N rows,
+// BASELINE config 4 and 'constraint_everywhere').  Round 5.  What it replaces there: the layer-by-layer
+// GEMM chain, whose activations, derivatives and deltas make six round trips of M x 256 floats through HBM per pass (7.8 GB of
+// the 36 GB a 5 461-instance sub-batch of config 4 moves per solve), and the four-wave k_mlp_fused above, which is 1.7 x faster
+// than that chain alone on the GPU (1.32 vs 2.20 ms over 218 440 rows) but whose blocks -- four wavefronts and 38 KB of LDS at
+// once on one CU -- wait behind resident QP wavefronts inside the closed loop (A/B in one session: C4 24.4 -> 23.9 ms per step,
+// 'constraint_everywhere' on C1 3.96 -> 4.03).  A block here is ONE wavefront that owns 16 rows through the whole pass and fits
+// the hole one retired QP wavefront leaves: < 256 registers, 16.7 KB of LDS.
+//   * v_mfma_f32_16x16x4_f32, the tiling of k_mlp_fused (four 16-column tiles taken with stride 4, so that one 16-byte load per
+//     lane fetches the B operands of all four): the wavefront walks the four 64-column groups of a 256-wide layer one after the
+//     other; the A operand (the layer's input, 16 x 256) sits in ONE LDS buffer, the layer's output stays in 64 registers until
+//     the last group has read the input, then overwrites it.
+//   * the activation derivatives of the three hidden layers (16 x 256 each) go through the per-layer buffers the GEMM chain
+//     already had ([M][256] floats, written in the forward half and read back by the same wavefront some 100 us later: L2 /
+//     Infinity Cache traffic mostly, 3 KB per row instead of the chain's 18 KB);
+//   * weights stream from L2, three 16-deep K chunks in flight (a chunk's 16 MFMAs last 512 cycles).
+// Same arithmetic and summation order as k_mlp_fused; H = 256, three hidden layers (the reference's NeuralNetwork,
+// safe_set.py:26-43).
+template <int NQ, bool BWD>
+__global__ __launch_bounds__(64) void k_mlp_wave(const smpc_problem_desc* __restrict__ D, int M, int N, int mode, int act,
+                                                 MlpWeights Wt, const double* __restrict__ xg, const double* __restrict__ p,
+                                                 const int32_t* __restrict__ idx, const int32_t* __restrict__ m_live,
+                                                 float* __restrict__ y_out, double* __restrict__ ev_out, int compact,
+                                                 float* __restrict__ dg0, float* __restrict__ dg1, float* __restrict__ dg2) {
+    constexpr int H = MLPF_H, LD = MLPF_LD, R = MLPF_ROWS;
+    __shared__ __attribute__((aligned(16))) float buf[R * LD];       // the current layer's input (features / activations / deltas)
+    __shared__ float sy[R];
+    const int lane = threadIdx.x, j = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * R;
+    const int live = m_live ? *m_live : M;
+    if (m0 >= live) return;
+    auto wave_sync = [&]() {       // LDS hand-off inside one wavefront: its LDS operations execute in order, the compiler must not reorder them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // ---- features (safe_set.py:82-87), one lane per row, into the head of the buffer with row stride MLP_KPAD
+    if (lane < R) {
+        const int m = m0 + lane;
+        float* sf = buf + lane * MLP_KPAD;
+#pragma unroll
+        for (int i = 0; i < MLP_KPAD; i++) sf[i] = 0.0f;
+        if (m < live) {
+            const double* x = xg + nn_row_to_node(mode, N, m, idx) * (2 * NQ);
+            const int nd = D->nn_dof;
+            double v[NQ], vn2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                v[i] = i < nd ? x[NQ + i] + (i == 0 ? D->nn_eps : 0.0) : 0.0;
+                vn2 += v[i] * v[i];
+            }
+            const double inv = 1.0 / sqrt(vn2);
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+                if (i < nd) {
+                    sf[i] = (float)((x[i] - D->nn_mean[i]) / D->nn_std[i]);
+                    sf[nd + i] = (float)(v[i] * inv);
+                }
+        }
+    }
+    wave_sync();
+    f32x4 acc[4];
+    float outH[4][4][4];                                     // [column group][tile][row register]: the layer's output
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) acc[tt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    };
+    auto chunk = [&](const f32x4 av, const f32x4* bv) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bv[r][tt], acc[tt], 0, 0, 0);
+        }
+    };
+    // acc += In[16 x K] * Bm[K x 256] over the columns c0 .. c0 + 3 of this lane (one per tile); In in LDS, Bm row-major, 256 columns
+    auto gemm = [&](int ld_in, const float* __restrict__ Bm, int K, int c0) {
+        const float* arow = buf + j * ld_in + 4 * kq;
+        const float* brow = Bm + (size_t)(4 * kq) * H + c0;
+        f32x4 bq[4][4];
+        auto bload = [&](f32x4* bv, int c) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) bv[r] = *reinterpret_cast<const f32x4*>(brow + (size_t)(16 * c + r) * H);
+        };
+        bload(bq[0], 0);
+        if (K == 16) {
+            chunk(*reinterpret_cast<const f32x4*>(arow), bq[0]);
+            return;
+        }
+        const int nch = K >> 4;
+        bload(bq[1], 1);
+        bload(bq[2], 2);
+        bload(bq[3], 3);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < nch; c += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                chunk(*reinterpret_cast<const f32x4*>(arow + 16 * (c + q)), bq[q]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + q + 4 < nch) bload(bq[q], c + q + 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // C/D map of a 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + register.  A lane's four tiles of a group are the four
+    // consecutive columns c0 .. c0 + 3: one 16-byte access per row.
+    auto rows_to_lds = [&]() {                                  // outH -> buf[row][column], every group
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                *reinterpret_cast<f32x4*>(buf + (4 * kq + r) * LD + 64 * g + 4 * j) = f32x4{outH[g][0][r], outH[g][1][r], outH[g][2][r], outH[g][3][r]};
+    };
+    auto dg_ptr = [&](float* base, int g, int r) -> f32x4* {    // derivative of (row 4 kq + r, columns of group g) in its layer's buffer
+        return reinterpret_cast<f32x4*>(base + (size_t)(m0 + 4 * kq + r) * H + 64 * g + 4 * j);
+    };
+    // ---- forward: three hidden layers
+    auto forward_layer = [&](auto ltag, int ld_in, int K, float* dgl) {
+        constexpr int l = decltype(ltag)::value;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int c0 = 64 * g + 4 * j;
+            zero_acc();
+            gemm(ld_in, Wt.wf[l], K, c0);
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(Wt.bias[l] + c0);
+            float dv[4][4];
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) outH[g][tt][r] = act_f(act, acc[tt][r] + bs[tt], &dv[tt][r]);
+            if (BWD) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) *dg_ptr(dgl, g, r) = f32x4{dv[0][r], dv[1][r], dv[2][r], dv[3][r]};
+            }
+        }
+        wave_sync();            // (every group has read the layer's input)
+        rows_to_lds();
+        wave_sync();
+    };
+    forward_layer(std::integral_constant<int, 0>{}, MLP_KPAD, MLP_KPAD, dg0);
+    forward_layer(std::integral_constant<int, 1>{}, LD, H, dg1);
+    forward_layer(std::integral_constant<int, 2>{}, LD, H, dg2);
+    // ---- output layer: y = a . w3 + b3 (four lanes per row, 64 columns each)
+    {
+        const int row = lane >> 2, part = lane & 3;
+        const float* a = buf + row * LD + 64 * part;
+        const float* w3 = Wt.wb[3] + 64 * part;              // (the last layer's W is [1][H])
+        float sacc = 0.0f;
+#pragma unroll 8
+        for (int c = 0; c < 64; c++) sacc = fmaf(a[c], w3[c], sacc);
+        sacc += __shfl_xor(sacc, 1);
+        sacc += __shfl_xor(sacc, 2);
+        if (part == 0) {
+            const float yv = sacc + Wt.bias[3][0];
+            sy[row] = yv;
+            if (y_out && m0 + row < live) y_out[m0 + row] = yv;
+        }
+    }
+    if (!BWD) return;
+    wave_sync();
+    // ---- backward: delta2 = w3 (.) act'(z2); delta1 = (delta2 W2) (.) act'(z1); delta0 = (delta1 W1) (.) act'(z0)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const f32x4 w3 = *reinterpret_cast<const f32x4*>(Wt.wb[3] + 64 * g + 4 * j);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const f32x4 dv = *dg_ptr(dg2, g, r);
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) outH[g][tt][r] = w3[tt] * dv[tt];
+        }
+    }
+    rows_to_lds();
+    wave_sync();
+    auto backward_layer = [&](const float* __restrict__ Wb, float* dgl) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            f32x4 dv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) dv[r] = *dg_ptr(dgl, g, r);      // (issued before the product: it has 256 MFMAs to arrive in)
+            zero_acc();
+            gemm(LD, Wb, H, 64 * g + 4 * j);
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) outH[g][tt][r] = acc[tt][r] * dv[r][tt];
+        }
+        wave_sync();
+        rows_to_lds();
+        wave_sync();
+    };
+    backward_layer(Wt.wb[2], dg1);
+    backward_layer(Wt.wb[1], dg0);
+    // ---- input gradient: GS[16 x 16] = delta0 [16 x 256] * W0 [256 x MLP_NPAD], columns 0 .. 15
+    f32x4 gsv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const float* arow = buf + j * LD + 4 * kq;
+        const float* bcol = Wt.wb[0] + (size_t)(4 * kq) * MLP_NPAD + j;
+#pragma unroll 4
+        for (int c = 0; c < H / 16; c++) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * c);
+#pragma unroll
+            for (int r = 0; r < 4; r++) gsv = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], bcol[(size_t)(16 * c + r) * MLP_NPAD], gsv, 0, 0, 0);
+        }
+    }
+    wave_sync();                                             // (the last product has read the buffer: its head now takes GS[16][16])
+#pragma unroll
+    for (int r = 0; r < 4; r++) buf[(4 * kq + r) * 16 + j] = gsv[r];
+    wave_sync();
+    // ---- chain rule back to the state (safe_set.py:82-94) and the per-node switch (utils.py:207-210): nn_val, nn_grad
+    if (lane < R && m0 + lane < live) {
+        const int m = m0 + lane;
+        const long node = nn_row_to_node(mode, N, m, idx);
+        const double* x = xg + node * (2 * NQ);
+        const double* pk = p + node * SMPC_NP;
+        if (pk[4] > 0.0) {                                   // (switched off: the row sits mid-bounds, (0, 0) is left)
+            double* const o = compact ? ev_out + (compact == 2 ? node / (N + 1) : node) * (1 + 2 * NQ) : ev_node(ev_out, node);      // (see k_nn_chain)
+            const long es = compact ? 1 : EV_TILE;
+            const int o_val = compact ? 0 : SMPC_EV_OFF(nn_val), o_grad = compact ? 1 : SMPC_EV_OFF(nn_grad);
+            const int nd = D->nn_dof;
+            float gs[MLP_KPAD];
+#pragma unroll
+            for (int i = 0; i < MLP_KPAD; i++) gs[i] = buf[lane * 16 + i];
+            double v[NQ], vn2 = 0.0, gdv = 0.0;
+#pragma unroll
+            for (int i = 0; i < NQ; i++) {
+                v[i] = i < nd ? x[NQ + i] + (i == 0 ? D->nn_eps : 0.0) : 0.0;
+                vn2 += v[i] * v[i];
+            }
+            const double vn = sqrt(vn2);
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+                if (i < nd) gdv += (double)gs[nd + i] * v[i];
+            const double kap = (100.0 - pk[3]) / 100.0;
+            o[o_val * es] = (double)sy[lane] * kap - vn;
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+                if (i < nd) {
+                    o[(o_grad + i) * es] = kap * (double)gs[i] / D->nn_std[i];
+                    o[(o_grad + NQ + i) * es] = kap * ((double)gs[nd + i] / vn - v[i] * gdv / (vn * vn * vn)) - v[i] / vn;
+                }
+        }
+    }
+}
+
 }  // namespace smpc

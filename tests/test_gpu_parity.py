@@ -565,40 +565,58 @@ def test_eval_nodes_device_path_matches_host_path():
         assert np.array_equal(np.asarray(a[f]), b[f].cpu().numpy()), f
 
 
-def test_mlp_tiled_gemm_kernel_in_a_child_process():
-    """The 128 x 128 LDS-tiled GEMM kernel is no longer the default for large row counts (round 4: one-wave blocks of k_gemm_f32,
-    DESIGN section 4) but stays selectable with SMPC_MLP_GEMM=tiled for A/B runs; the knob is read once per process, so the
-    kernel is exercised in a child process running test_mlp_layer_by_layer_gemm_path."""
+def test_mlp_layer_by_layer_gemm_kernels_in_child_processes():
+    """From 8 192 network rows on the default is the one-wave fused kernel (k_mlp_wave, round 5); the layer-by-layer GEMM chain of
+    rounds 1-4 stays selectable (SMPC_MLP_LARGE=chain: one-wave blocks of k_gemm_f32; with SMPC_MLP_GEMM=tiled on top the 128 x 128
+    LDS-tiled kernel) for A/B runs and for networks that are not 256 wide with three hidden layers.  The knobs are read once per
+    process, so both chains are exercised in child processes running the large-row tests of this file."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SMPC_MLP_GEMM='tiled')
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x', '-k',
-                        'test_mlp_layer_by_layer_gemm_path'], env=env, cwd=root, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert '1 passed' in r.stdout
+    for extra in ({'SMPC_MLP_LARGE': 'chain'}, {'SMPC_MLP_LARGE': 'chain', 'SMPC_MLP_GEMM': 'tiled'}):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x', '-k',
+                            'test_mlp_large_row_counts or test_mlp_activations_fused_and_large_paths'], env=env, cwd=root, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, (extra, r.stdout[-2000:] + r.stderr[-2000:])
+        assert '7 passed' in r.stdout, (extra, r.stdout[-500:])
 
 
-def test_mlp_layer_by_layer_gemm_path():
-    """The safe-set row on every node of 512 instances x 16 stages = 8 192 MLP rows: the layer-by-layer GEMM kernels (from that
-    row count on also the LDS-tiled one when SMPC_MLP_GEMM=tiled)."""
+@pytest.mark.parametrize('switched', [False, True])
+def test_mlp_large_row_counts(switched):
+    """The safe-set row on every node of 520 instances x 16 stages = 8 320 MLP rows: the large-row path (default: k_mlp_wave, one-wave
+    blocks of 16 rows; the GEMM chain in the child processes above).  `switched`: the per-node switch p[4] random, so the rows are a
+    compacted list (mode 3) whose length is not a multiple of a block's 16 rows, and the switched-off nodes' slots must stay zero."""
     par, prob, net = make_problem('constraint_everywhere', 'ext', N=16)
     s, o = _solver(prob, net), _oracle(prob, net)
-    B = 512
+    B = 520
     x0 = sample_instances(prob, B, seed=6, vel_scale=0.3)
     xg, ug, p = constant_guess(prob, x0)
-    xg[:, 1:] += 0.05 * np.random.default_rng(0).standard_normal(xg[:, 1:].shape)
+    rng = np.random.default_rng(0)
+    xg[:, 1:] += 0.05 * rng.standard_normal(xg[:, 1:].shape)
+    if switched:
+        p[:, :, 4] = np.where(rng.uniform(size=p.shape[:2]) < 0.55, 1.0, -1.0)
+        if int((p[:, 1:, 4] > 0).sum()) % 16 == 0:
+            p[np.unravel_index(np.argmax(p[:, 1:, 4] > 0), p[:, 1:, 4].shape)[0], 1 + np.unravel_index(np.argmax(p[:, 1:, 4] > 0), p[:, 1:, 4].shape)[1], 4] = -1.0
+        assert int((p[:, 1:, 4] > 0).sum()) % 16 != 0
     a, b = s.eval_nodes(xg, ug, p), o.eval_nodes(xg, ug, p)
     assert _rel(a['nn_val'], b['nn_val']) < 2e-5
     assert _rel(a['nn_grad'][..., :12], b['nn_grad'][..., :12]) < 2e-4
+    if switched:
+        off = p[:, :, 4] <= 0
+        assert np.all(a['nn_val'][off] == 0.0) and np.all(a['nn_grad'][off] == 0.0) and np.abs(a['nn_val'][~off][:, None]).max() > 0
+    # ... and through the solve (the stage builder reads the compact per-node buffer the kernel writes)
+    xa, ua, sa, ia = s.solve(x0[:64], xg[:64], ug[:64], p[:64])       # (64 x 16 rows: the small-row kernel -- same numbers expected)
+    xb, ub, sb, ib = o.solve_batch(x0[:64], xg[:64], ug[:64], p[:64])
+    assert np.array_equal(sa, sb)
 
 
 @pytest.mark.parametrize('act', ['gelu', 'relu', 'elu', 'tanh', 'silu'])
-def test_mlp_activations_fused_and_tiled_paths(act):
+def test_mlp_activations_fused_and_large_paths(act):
     """VERDICT r2 item 7 / missing #3: every activation of parser.py:95-102 on the engine, through the fused small-batch
-    kernel (terminal row: one launch for the whole network pass) and through the layer-by-layer GEMM kernels (row on every
-    node, 8 192 rows: LDS-tiled), against the oracle's fp32 loops."""
+    kernel (terminal row: one launch for the whole network pass) and through the large-row path (row on every node, 8 192 rows:
+    k_mlp_wave by default, the GEMM chains in test_mlp_layer_by_layer_gemm_kernels_in_child_processes), against the oracle's fp32 loops."""
     for controller, B, N in (('st', 96, 12), ('constraint_everywhere', 512, 16)):
         par, prob, net = make_problem(controller, 'ext', N=N, act=act)
         from oracle.oracle import Oracle
