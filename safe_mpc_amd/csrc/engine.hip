@@ -375,8 +375,12 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
 // experiment knob: extra dynamic LDS per block of k_qp_ipm limits how many wavefronts are resident per CU (the rest queue
 // behind the longest-first order and backfill)
 static size_t qp_pad_lds() {
+#ifdef SMPC_EXPERIMENTS     // (experiment builds only: make FLAGS+=-DSMPC_EXPERIMENTS; the shipped library reads no such knob on its solve path)
     static const size_t v = [] { const char* e = getenv("SMPC_QP_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
     return v;
+#else
+    return 0;
+#endif
 }
 
 // k_qp_ipm's non-temporal variant: -1 (default) by workspace size, 0 / 1 forced (SMPC_QP_NT, A/B runs).  The threshold sits between
@@ -404,7 +408,11 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
     const long bstride = per_inst ? (long)(h->N + 1) * 2 * h->desc.nq : 0L;
     // experiment knob: the linearisation (+ network pass) and / or the set-up launched once more, to measure what
     // a stream's chain pays for them inside the loop (bit 0: linearisation, bit 1: set-up; old path only)
+#ifdef SMPC_EXPERIMENTS
     static const int dup = [] { const char* e = getenv("SMPC_DUP_KERNELS"); return e ? atoi(e) : 0; }();
+#else
+    constexpr int dup = 0;
+#endif
     if (path == 1) {
         if ((rc = launch_nn<NQ>(h, B, xg, p, h->d_nn, h->desc.nn_mode == SMPC_NN_TERMINAL ? 2 : 1))) return rc;
         if (timed) HIPCHK(h, hipEventRecord(h->ev_t[1], h->stream));
@@ -412,7 +420,11 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
         const dim3 grd((unsigned)((nodes + 64 / SB_G - 1) / (64 / SB_G))), blk(64);
         const double* nn = h->desc.nn_mode != SMPC_NN_NONE ? h->d_nn : nullptr;
         // (experiment knob: extra dynamic LDS per block of the builder -- how much its start depends on LDS room next to QP wavefronts)
+#ifdef SMPC_EXPERIMENTS
         static const size_t sb_pad = [] { const char* e = getenv("SMPC_SB_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+#else
+        constexpr size_t sb_pad = 0;
+#endif
 #define SMPC_SB_LAUNCH(MR_)                                                                                                       \
         hipLaunchKernelGGL((k_stage_build<NQ, MR_>), grd, blk, sb_pad, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi, h->d_zl, nn,     \
                            h->d_ws, bstride, h->d_active)

@@ -69,7 +69,8 @@ for g in groups:
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 B = sum(g['n'] for g in groups)
-acc = sum(g['acc'].cpu().numpy() for g in groups)
+acc_g = [g['acc'].cpu().numpy().copy() for g in groups]        # (per group, before the event-timed continuation of the loop adds to them)
+acc = sum(acc_g)
 
 
 def sync():
@@ -83,8 +84,21 @@ def sync():
 tk = bench.in_loop_kernel_times([g['sv'] for g in groups], step, sync, max(steps, 6))
 names = ['linearise', 'mlp', 'qp_setup', 'qp_ipm', 'solve_total']
 in_loop = {str(g['N']): {n_: float(t_[i]) for i, n_ in enumerate(names)} for g, t_ in zip(groups, tk) if t_ is not None}
+# HBM traffic: k_qp_ipm<6,6,*> moves a fixed number of bytes per STAGE and iteration, so the C1 measurement (31 stages,
+# profiles/r05_pmc_traffic.json) gives bytes per instance-iteration at horizon N as x (N + 1) / 31; weighted with the loop's own
+# instance-iterations of every horizon group
+bpi31, tsrc = None, None
+tf = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
+if os.path.exists(tf):
+    bpi31, tsrc = json.load(open(tf)).get('bytes_per_instance_iteration'), 'profiles/r05_pmc_traffic.json (x (N + 1) / 31 per horizon group)'
+its = [float(a_[0]) / steps for a_ in acc_g]                                     # instance-iterations per step, per group
 roof = bench.roofline_of_launches([bench.algorithmic_bytes(6, g['N']) * g['n'] for g, t_ in zip(groups, tk) if t_ is not None],
                                   [t_[3] for t_ in tk if t_ is not None])
+if bpi31:
+    tr = sum(bpi31 * (g['N'] + 1) / 31.0 * it_ for g, it_ in zip(groups, its))   # bytes per step over all groups' launches
+    roof['traffic'] = tr / max(len(groups), 1)
+    roof['traffic_source'], roof['traffic_bytes_per_instance_iteration_at_N30'] = tsrc, bpi31
+    roof['wasted_traffic_ratio'] = roof['traffic'] / roof['algorithmic_bytes_per_launch']
 roof['algorithmic_bytes_per_instance_step'] = {str(g['N']): bench.algorithmic_bytes(6, g['N']) for g in groups}
 print(json.dumps({'roofline': roof, 'kernel_ms_in_loop_by_horizon': in_loop,'workload': 'C3: rank %d of 8 of the 32768-instance horizon x alpha grid (N in 20..40, alpha in 20..50), controller %s' % (rank, bench.CONTROLLER),
                   'instances': B, 'groups': {str(g['N']): g['n'] for g in groups}, 'steps': steps, 'warmup': warm,

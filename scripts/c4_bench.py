@@ -78,7 +78,19 @@ tk = bench.in_loop_kernel_times([g['sv'] for g in groups], step, sync, max(steps
 names = ['linearise', 'mlp', 'qp_setup', 'qp_ipm', 'solve_total']
 in_loop = {n_: float(np.mean([t_[i] for t_ in tk if t_ is not None])) for i, n_ in enumerate(names)}
 alg1 = bench.algorithmic_bytes(nq, N)
-roof = bench.roofline_of_launches([alg1 * g['n'] for g, t_ in zip(groups, tk) if t_ is not None], [t_[3] for t_ in tk if t_ is not None])
+# HBM traffic of the dominant kernel: bytes per instance-iteration of k_qp_ipm<7,4,true> from the rocprofv3 --pmc passes over this very
+# problem (scripts/prof_pmc.sh <dir> c4 -> profiles/r05_pmc_traffic_c4.json) x the loop's own instance-iterations per launch
+bpi, tsrc = None, None
+tf = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic_c4.json')
+if os.path.exists(tf):
+    bpi, tsrc = json.load(open(tf)).get('bytes_per_instance_iteration'), 'profiles/r05_pmc_traffic_c4.json'
+n_launch = len([t_ for t_ in tk if t_ is not None])
+roof = bench.roofline_of_launches([alg1 * g['n'] for g, t_ in zip(groups, tk) if t_ is not None], [t_[3] for t_ in tk if t_ is not None],
+                                  bpi, (float(acc[0]) / steps) if bpi else None)
+roof['traffic_source'], roof['traffic_bytes_per_instance_iteration'] = tsrc, bpi
+if roof.get('traffic'):
+    roof['wasted_traffic_ratio'] = roof['traffic'] / roof['algorithmic_bytes_per_launch']
+    roof['traffic_GBps'] = roof['traffic'] / (roof['avg_launch_ms'] * 1e-3) / 1e9
 roof['algorithmic_bytes_per_instance_step'] = alg1
 print(json.dumps({'roofline': roof, 'kernel_ms_in_loop': in_loop,'workload': 'C4: 7-DoF Franka-class, N=40, %d instances (one GPU of 8 x 16384), controller %s, sphere + floor rows, NN row on every node' % (B, CONT),
                   'instances': B, 'streams': S, 'steps': steps, 'warmup': warm, 'ms_per_step': 1e3 * dt / steps,

@@ -31,7 +31,10 @@ def main(argv=None):
     res = cl.run_mpc(params, cont_name, x_guess, u_guess, noise=args['noise'], control_noise=args['control_noise'],
                      callback=True, on_device=os.environ.get('SMPC_HOST_STATE', '0') != '1', timing=tm,
                      collect_times=os.environ.get('SMPC_NO_TIME_STATS', '0') != '1')
-    print(f"{tm['ms_per_step']:.3f} ms per closed-loop step of {x_guess.shape[0]} instances")
+    with_stats = os.environ.get('SMPC_NO_TIME_STATS', '0') != '1'
+    print(f"{tm['ms_per_step']:.3f} ms per closed-loop step of {x_guess.shape[0]} instances"
+          + (' (eager launches with per-solve HIP events for the time statistics below; SMPC_NO_TIME_STATS=1 replays the step halves as '
+             'hipGraphs without them)' if with_stats else ' (step halves replayed as hipGraphs, no per-solve time statistics)'))
     if 'time_stats' in res:      # the block of the reference's mpc.py:300-303 (here one solve = all instances of a group)
         print('99% quantile of the computation time:')
         for field, t in zip(res['time_fields'], res['time_q99']):
