@@ -60,6 +60,10 @@ struct smpc_handle {
     size_t capM = 0;
     float *d_S = nullptr, *d_y = nullptr, *d_GS = nullptr, *d_dA = nullptr, *d_dB = nullptr;
     int32_t *d_nn_idx = nullptr, *d_nn_cnt = nullptr;   // compacted list of the nodes whose safe-set row is on + its length
+                                // INVARIANT: *d_nn_cnt is zero whenever no chain of kernels is using it.  Every chain that fills it ends in
+                                // something that hands it back at zero -- on the solve path a kernel that runs anyway (k_stage_build after the
+                                // network pass, k_policy_post after the safe-set test), elsewhere a memset -- so the hot path has no memset
+                                // launch of its own, and a captured step can be replayed whatever ran in between
     size_t nn_idx_cap = 0;
     float* d_act[SMPC_MAX_LAYERS] = {nullptr};
     float* d_dg[SMPC_MAX_LAYERS] = {nullptr};
@@ -229,6 +233,7 @@ int ensure_nn_idx(smpc_handle* h, size_t M) {
     if ((rc = dev_alloc(h, &h->d_nn_idx, M + 1))) return rc;
     h->nn_idx_cap = M;
     h->d_nn_cnt = h->d_nn_idx + M;
+    HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), h->stream));
     return SMPC_OK;
 }
 
@@ -342,7 +347,6 @@ int launch_nn(smpc_handle* h, int B, const double* d_xg, const double* d_p, doub
     int rc;
     if (mode == 3) {
         if ((rc = ensure_nn_idx(h, (size_t)M))) return rc;
-        HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
         hipLaunchKernelGGL(k_nn_compact, dim3((M + 63) / 64), dim3(64), 0, s, M, N, d_p, h->d_nn_idx, h->d_nn_cnt);
     }
     bool chained = false;
@@ -368,6 +372,8 @@ int launch_eval(smpc_handle* h, int B, const double* d_xg, const double* d_ug, c
     if (timed) HIPCHK(h, hipEventRecord(h->ev_t[1], s));
     int rc;
     if ((rc = launch_nn<NQ>(h, B, d_xg, d_p, d_ev, 0))) return rc;
+    // (this path has no stage builder behind the network pass to hand the row list's counter back at zero: see d_nn_cnt)
+    if (h->desc.nn_mode == SMPC_NN_ALL && h->d_nn_cnt) HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
     if (timed) HIPCHK(h, hipEventRecord(h->ev_t[2], s));
     return SMPC_OK;
 }
@@ -419,6 +425,7 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
         const long nodes = (long)B * (h->N + 1);
         const dim3 grd((unsigned)((nodes + 64 / SB_G - 1) / (64 / SB_G))), blk(64);
         const double* nn = h->desc.nn_mode != SMPC_NN_NONE ? h->d_nn : nullptr;
+        int32_t* const zero_cnt = h->desc.nn_mode == SMPC_NN_ALL ? h->d_nn_cnt : nullptr;     // (the builder hands the list's counter back at zero)
         // (experiment knob: extra dynamic LDS per block of the builder -- how much its start depends on LDS room next to QP wavefronts)
 #ifdef SMPC_EXPERIMENTS
         static const size_t sb_pad = [] { const char* e = getenv("SMPC_SB_PAD_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
@@ -427,7 +434,7 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
 #endif
 #define SMPC_SB_LAUNCH(MR_)                                                                                                       \
         hipLaunchKernelGGL((k_stage_build<NQ, MR_>), grd, blk, sb_pad, h->stream, h->d_desc, B, h->N, x0, xg, ug, p, blo, bhi, h->d_zl, nn,     \
-                           h->d_ws, bstride, h->d_active)
+                           h->d_ws, bstride, h->d_active, zero_cnt)
         switch (h->desc.n_rows) {
         case 6: SMPC_SB_LAUNCH(6); break;
         case 4: SMPC_SB_LAUNCH(4); break;
@@ -555,7 +562,7 @@ int upload_check_bounds(smpc_handle* h, const double* x_min, const double* x_max
 // state test (+ safe-set test if d_nn) of B trajectories of n_nodes nodes on the device, against the uploaded check bounds;
 // collision rows on the leading coll_nodes nodes only
 int check_nodes_dev(smpc_handle* h, int B, int n_nodes, const double* d_x, double tol_x, int coll_nodes, double alpha,
-                    double tol_safe, int32_t* d_ok, int32_t* d_nn, bool nn_listed = false) {
+                    double tol_safe, int32_t* d_ok, int32_t* d_nn, bool nn_listed = false, bool ok_prefilled = false) {
     const int nq = h->desc.nq, nx = 2 * nq;
     hipStream_t s = h->stream;
     const size_t M = (size_t)B * n_nodes;
@@ -563,7 +570,8 @@ int check_nodes_dev(smpc_handle* h, int B, int n_nodes, const double* d_x, doubl
     double* d_max = d_min + nx;
     double* d_rlb = d_max + nx;
     double* d_rub = d_rlb + SMPC_MAX_ROWS;
-    HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)d_ok, 1, (size_t)B, s));   // verdicts start at "ok", stream-ordered
+    // verdicts start at "ok", stream-ordered (smpc_policy_step: an earlier kernel of the step has done it)
+    if (!ok_prefilled) HIPCHK(h, hipMemsetD32Async((hipDeviceptr_t)d_ok, 1, (size_t)B, s));
     // (one wavefront per block throughout the small kernels: a multi-wave block needs room on several SIMDs of ONE CU at the
     //  same moment, and next to resident QP wavefronts -- 256 registers each, two fill a SIMD -- it waited for that up to a
     //  millisecond: k_policy_post, six blocks of four waves, averaged 131 us in the three-stream loop; rocprofv3, round 3)
@@ -909,7 +917,7 @@ int smpc_guess_correction(smpc_handle* h, int B, double* xg, const double* ug, i
         du = duw;
     }
     hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 63) / 64), dim3(64), 0, s, B, N, nq, h->desc.dt, dx, du, (const uint8_t*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, (int32_t*)nullptr);
     HIPCHK(h, hipGetLastError());
     if (!on_device) {
         HIPCHK(h, hipMemcpyAsync(xg, dx, sizeof(double) * B * (N + 1) * nx, hipMemcpyDeviceToHost, s));
@@ -1207,7 +1215,7 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
     // non-empty (B > 0, nq > 0), so thread 0 of block 0 always exists.
     if (kind != SMPC_POLICY_REAL_RECEDING)
         hipLaunchKernelGGL(k_guess_correction, dim3((B * nq + 63) / 64), dim3(64), 0, s, B, N, nq, h->desc.dt, st->x_guess,
-                           st->u_guess, stepping, any_abort);
+                           st->u_guess, stepping, any_abort, d_ok);
     if (receding) {
         if (kind == SMPC_POLICY_REAL_RECEDING) {
             const size_t n = (size_t)B * (N + 1) * nx;
@@ -1224,7 +1232,8 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
         }
         hipLaunchKernelGGL(k_policy_pre, dim3((unsigned)(((size_t)B * (N + 1) + 63) / 64)), dim3(64), 0, s, B, N, nx, kind,
                            stepping, st->r, st->p, st->x_guess, par->stage_lo, par->stage_hi, par->tube, h->d_lo_b, h->d_hi_b,
-                           kind == SMPC_POLICY_REAL_RECEDING ? any_abort : (int32_t*)nullptr);
+                           kind == SMPC_POLICY_REAL_RECEDING ? any_abort : (int32_t*)nullptr,
+                           kind == SMPC_POLICY_REAL_RECEDING ? d_ok : (int32_t*)nullptr);
     }
     if (st->traj) {      // controller.py:153-156: the nodes' reference points follow the step counter
         if (st->traj_len < 1) return fail(h, SMPC_EINVAL, "traj_len must be >= 1");
@@ -1243,16 +1252,17 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
             // the safe-set test is only ever read at nodes r + 2 .. N of the stepping instances (k_policy_post): list them
             const size_t M = (size_t)B * (N + 1);
             if ((rc = ensure_nn_idx(h, M))) return rc;
-            HIPCHK(h, hipMemsetAsync(h->d_nn_cnt, 0, sizeof(int32_t), s));
             hipLaunchKernelGGL(k_policy_safe_list, dim3((unsigned)((M + 63) / 64)), dim3(64), 0, s, B, N, par->abort_flag, stepping, st->r,
                                h->d_nn_idx, h->d_nn_cnt);
         }
         if ((rc = check_nodes_dev(h, B, N + 1, st->x_temp, par->tol_x, coll, par->alpha, par->tol_safe, d_ok, receding ? d_safe : nullptr,
-                                  receding)))
+                                  receding, true)))
             return rc;
     }
     hipLaunchKernelGGL(k_policy_post, dim3((B + 63) / 64), dim3(64), 0, s, B, N, nx, kind, par->abort_flag, stepping, st->status,
-                       d_ok, d_safe, st->x_guess, st->fails, st->current_step, st->r, st->x_viable, d_acc, d_act, abort_out, any_abort);
+                       d_ok, d_safe, st->x_guess, st->fails, st->current_step, st->r, st->x_viable, d_acc, d_act, abort_out, any_abort,
+                       (receding && kind != SMPC_POLICY_NAIVE) ? h->d_nn_cnt : (int32_t*)nullptr);
+
     hipLaunchKernelGGL(k_provide_control, dim3((B * (nx + nq) + 63) / 64), dim3(64), 0, s, B, N, nq, d_acc, st->x_temp, st->u_temp,
                        st->x_guess, st->u_guess, u_out, stepping, d_act, u_other);
     HIPCHK(h, hipGetLastError());

@@ -660,10 +660,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SB_WAVES, SB
                                                     const double* __restrict__ xg, const double* __restrict__ ug, const double* __restrict__ pp,
                                                     const double* __restrict__ lo_st, const double* __restrict__ hi_st,
                                                     const double* __restrict__ zl_st, const double* __restrict__ nn, double* __restrict__ ws_all,
-                                                    long bnd_stride, const uint8_t* __restrict__ active) {
+                                                    long bnd_stride, const uint8_t* __restrict__ active, int32_t* __restrict__ zero_cnt) {
     constexpr int NX = 2 * NQ, NU = NQ;
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS;
     using LD = SbLds<NQ, MR_MAX>;
+    // (the length of the network pass's compacted row list: the pass ran before this kernel on the same stream, so the counter can be
+    //  handed back at zero for the next solve's k_nn_compact -- one memset launch fewer in the chain)
+    if (zero_cnt && blockIdx.x == 0 && threadIdx.x == 0) *zero_cnt = 0;
     constexpr int NODES = 64 / SB_G;
     __shared__ __attribute__((aligned(16))) double smem[NODES * LD::SIZE];
     const int g = threadIdx.x & (SB_G - 1), grp = threadIdx.x / SB_G;

@@ -9,14 +9,17 @@ namespace smpc {
 // with mask[b] == 0 are left alone (the policy layer: instances that do not step their controller this time).
 // zero_flag (may be null): one int32 this launch resets -- smpc_policy_step's any_abort, which a later kernel of the same step
 // raises with atomics (a hipMemsetAsync would be one more launch in a chain of short ones)
+// ok_fill (may be null): [B] verdicts of the state test that follows the solve, set to "ok" here (one fill launch fewer in the chain)
 __global__ void k_guess_correction(int B, int N, int nq, double dt, double* __restrict__ xg,
-                                   const double* __restrict__ ug, const uint8_t* __restrict__ mask, int32_t* __restrict__ zero_flag) {
+                                   const double* __restrict__ ug, const uint8_t* __restrict__ mask, int32_t* __restrict__ zero_flag,
+                                   int32_t* __restrict__ ok_fill) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 && zero_flag) *zero_flag = 0;
     if (t >= (long)B * nq) return;
     const long b = t / nq;
-    if (mask && !mask[b]) return;
     const int i = (int)(t % nq);
+    if (ok_fill && i == 0) ok_fill[b] = 1;
+    if (mask && !mask[b]) return;
     const int nx = 2 * nq;
     double* x = xg + b * (N + 1) * nx;
     const double* u = ug + b * N * nq;

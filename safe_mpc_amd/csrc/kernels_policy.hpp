@@ -13,12 +13,14 @@ namespace smpc {
 __global__ void k_policy_pre(int B, int N, int nx, int kind, const uint8_t* __restrict__ stepping,
                              const int64_t* __restrict__ r_all, double* __restrict__ p, const double* __restrict__ xg,
                              const double* __restrict__ lo_st, const double* __restrict__ hi_st, double tube,
-                             double* __restrict__ lo_b, double* __restrict__ hi_b, int32_t* __restrict__ zero_flag) {
+                             double* __restrict__ lo_b, double* __restrict__ hi_b, int32_t* __restrict__ zero_flag,
+                             int32_t* __restrict__ ok_fill) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 && zero_flag) *zero_flag = 0;       // (RealReceding has no guessCorrection launch to do this)
     if (t >= (long)B * (N + 1)) return;
     const long b = t / (N + 1);
     const int k = (int)(t - b * (N + 1));
+    if (ok_fill && k == 0) ok_fill[b] = 1;         // (... nor to start the state test's verdicts at "ok")
     if (stepping && !stepping[b]) return;
     const int r = (int)r_all[b];
     if (kind == SMPC_POLICY_RECEDING) {
@@ -85,8 +87,9 @@ __global__ void k_policy_post(int B, int N, int nx, int kind, int abort_flag, co
                               const int32_t* __restrict__ safe, const double* __restrict__ xg, int64_t* __restrict__ fails,
                               int64_t* __restrict__ current_step, int64_t* __restrict__ r_all, double* __restrict__ x_viable,
                               int32_t* __restrict__ accept, uint8_t* __restrict__ active, uint8_t* __restrict__ abort_out,
-                              int32_t* __restrict__ any_abort) {
+                              int32_t* __restrict__ any_abort, int32_t* __restrict__ zero_cnt) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && zero_cnt) *zero_cnt = 0;     // (the length of the safe-set test's node list: every kernel that read it has finished)
     if (b >= B) return;
     if (stepping && !stepping[b]) {
         accept[b] = 0;
