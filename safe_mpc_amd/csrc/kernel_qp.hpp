@@ -1434,7 +1434,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
 #pragma unroll
                         for (int j = 0; j < WST_PF; j++) d2[min(hl + 32 * j, W_N2 - 1)] = S.Ws[j];
                     }
-                    const double q1 = pvc[ip1], q2 = pvc[ip2];
+                    int i1 = ip1, i2 = ip2;
+                    if constexpr (NQ >= 7) {
+                        // (7-DoF: the two indices were spilled across the other sweeps and reloaded from scratch inside every stage of this
+                        //  one -- a scratch load in a stage body turns the counted waits into vmcnt(0); formed here from the lane index instead)
+                        int hh = hl;
+                        asm volatile("" : "+v"(hh));
+                        const int px = hh < NZ ? (hh >= NU ? hh - NU : 0) : NZ - 1 - NU;
+                        i1 = hh < NU ? hh : px;
+                        i2 = hh < NU ? NQ + hh : (px >= NQ ? px - NQ : 0);
+                    }
+                    const double q1 = pvc[i1], q2 = pvc[i2];
                     if (hl < NU) sRho[hl] = gh + cB * q1 + dt * q2;
                     load_b(S, kp);
                     lds_fence();

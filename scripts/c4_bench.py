@@ -2,7 +2,7 @@
 """BASELINE config 4 timed: one GPU's share (16 384 of 131 072 instances) of the 7-DoF Franka-class problem (config_fr7.yaml:
 N = 40, sphere obstacle + floor rows, safe-set row on EVERY node through the MLP, controller 'constraint_everywhere') as a closed
 loop on three sub-batch streams -- the same loop as bench.py.  Prints ms per step and instance-steps/s.
-    python scripts/c4_bench.py [steps] [warmup] [instances]"""
+    python scripts/c4_bench.py [steps] [warmup] [instances] [streams]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +19,7 @@ from safe_mpc_amd.solver import BatchedOcpSolver
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
-N, S, CONT = 40, 3, 'constraint_everywhere'
+N, S, CONT = 40, (int(sys.argv[4]) if len(sys.argv) > 4 else 3), 'constraint_everywhere'
 par = Parameters({}, 'fr7', filename=os.path.join(ROOT, 'config_fr7.yaml'))
 par.N = N
 prob = OcpProblem(par, CONT, 'ext', N=N)
