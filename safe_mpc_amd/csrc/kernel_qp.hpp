@@ -652,9 +652,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     const int c_n2 = Ly.nF >> 1;            // ... and of its part [Tt | Gt | gn | b | scalars] (what the forward sweeps fetch)
 
     // ---- LDS: one region per half-wave ---------------------------------------------------------------------------------
-    // [image | D | E | -- buffers of the factorisation sweep only: TD GD Lambda G Wt Hxx P P -- | vectors]
+    // [image | D | E | -- buffers of the factorisation sweep only: TD GD Lambda G Wt P P -- | vectors]
     constexpr int O_D = IMG_MAX, O_E = O_D + NL, O_TD = O_E + NL, O_GD = O_TD + NZ * NQP, O_LAM = O_GD + NQ * MRP_MAX,
-                  O_G = O_LAM + qp_even_c(NQ * NQ), O_WT = O_G + NQ * WS2, O_HXX = O_WT + (NX + 1) * NQP, O_PA = O_HXX + NX * NX,
+                  O_G = O_LAM + qp_even_c(NQ * NQ), O_WT = O_G + NQ * WS2, O_PA = O_WT + (NX + 1) * NQP,
                   O_PB2 = O_PA + NX * NX, O_PVA = O_PB2 + NX * NX, O_PVB = O_PVA + NX, O_PB = O_PVB + NX,
                   O_ZU = O_PB + NX, O_XB = O_ZU + NQP, O_RHO = O_XB + 2 * NX, O_WV = O_RHO + NQP, HALF_D = O_WV + NQP;
     __shared__ __attribute__((aligned(16))) double smem[2 * HALF_D];
@@ -674,9 +674,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     double* const sLam = sIMG + O_LAM;
     double* const sG = sIMG + O_G;
     double* const sWT = sIMG + O_WT;
-    double* const sWI = sIMG + O_HXX;   // B1: the factor block as it is stored (NX * NX doubles of room)
+    // B1 lays the factor block out as it is stored before storing it -- over Lambda and G, which are dead by then: the Cholesky
+    // factor sits in registers and every lane has read its column of [G | rho] (round 5: a buffer of NX * NX doubles of its own until
+    // then; without it the 7-DoF block is 21.6 KB instead of 24.7 and seven wavefronts fit a CU instead of six)
+    double* const sWI = sIMG + O_LAM;
     static_assert(CST_MAX + 2 * NWP <= O_PVA - O_TD, "staging area of the forward sweeps");
-    static_assert(NWP + NQ <= NX * NX, "B1 lays the factor block out in a buffer of its own before storing it");
+    static_assert(NWP + NQ <= qp_even_c(NQ * NQ) + NQ * WS2, "the stored image of the factor block fits over Lambda and G");
     double* const sCst = sIMG + O_TD;                      // forward sweeps only: general rows ...
     double* const sWstA = sIMG + O_TD + CST_MAX;           // ... and the factor block, double-buffered (B2: single)
     double* const sPB = sIMG + O_PB;
