@@ -6,12 +6,12 @@ FEASIBLE QPs reported infeasible (the penalty is exact only above the hard probl
 9 / 16 / 26 iterations, 27 / 21 / 7 false alarms.  The multipliers of an infeasible tube climb by ~x3 per iteration, so any test that
 is exact enough to spare the feasible QPs needs as many iterations as the stall exit.  usage: rr_elastic_replay.py <w or cap> ..."""
 import os, sys, pickle
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from conftest import make_problem
 from oracle.oracle import Oracle
-REC = pickle.load(open('/tmp/x/rr_rec.pkl','rb'))
+REC = pickle.load(open(os.environ.get('RR_REC', '/tmp/rr_rec.pkl'), 'rb'))
 N=30
 W = [float(a) for a in sys.argv[1:]] or [1e4]
 par, prob, net = make_problem('real_receding', N=N)

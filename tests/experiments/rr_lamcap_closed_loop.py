@@ -4,7 +4,7 @@
 A false alarm starts a cascade of its own, so the cap changes the policy's outcomes -- and the launch-bounding maximum hardly moves
 (QPs that are infeasible in other rows still run to the stall exit).  Not adopted."""
 import os, sys
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tests/experiments'))
 import numpy as np
 _a = sys.argv[:]; sys.argv = sys.argv[:1]

@@ -1,9 +1,9 @@
 """CPU experiment (oracle only): records every QP of a real_receding closed loop (256 instances x 56 steps) with its tube node,
-status and iteration count into /tmp/x/rr_rec.pkl, and prints where the failures are: a first failure at r = N - 1 (0.3 % of those
+status and iteration count into $RR_REC (default /tmp/rr_rec.pkl), and prints where the failures are: a first failure at r = N - 1 (0.3 % of those
 solves) starts a cascade -- the tube asks for the SAME absolute state one step earlier than the plan reaches it, so every following
 solve of that instance fails too until r = 0 aborts (controller.py:530-553): 843 of 14 336 solves fail, 803 of them in cascades."""
 import os, sys
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests')); sys.path.insert(0, os.path.join(ROOT, 'tests/experiments'))
 import numpy as np
 import rr_infeasible as R
@@ -40,5 +40,4 @@ print('iterations of ok: mean', it[~bad].mean(), 'max', it[~bad].max())
 dt = par.dt
 for (s_, j_) in zip(*np.where(bad)):
     pass
-np.save('/tmp/x/rr_rec.npy', np.array([0]))
-import pickle; pickle.dump(REC, open('/tmp/x/rr_rec.pkl','wb'))
+import pickle; pickle.dump(REC, open(os.environ.get('RR_REC', '/tmp/rr_rec.pkl'), 'wb'))
