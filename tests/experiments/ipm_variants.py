@@ -81,6 +81,10 @@ VARIANTS = [
     ('ftb gate .5', {'FTBGATE': 0.5}),
     ('ftb gate .9 ftb .999', {'FTBGATE': 0.9, 'FTB': 0.999}),
     ('ftb hi .999999', {'FTBHI': 0.999999}),
+    ('ftb .9', {'FTB': 0.9}),
+    ('ftb .95', {'FTB': 0.95}),
+    ('ftb .98', {'FTB': 0.98}),
+    ('ftb .99', {'FTB': 0.99}),
 ]
 if len(sys.argv) > 4:
     VARIANTS = [VARIANTS[0]] + [v for v in VARIANTS if any(a in v[0] for a in sys.argv[4:])]
