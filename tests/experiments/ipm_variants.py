@@ -19,6 +19,9 @@ Round 5 (128 instances x 100 closed-loop steps, 'st'; cost in units of one full 
   sigma cap .1 / pow 2 / pow 4: 1.022 / 1.034 / 0.997;  second-order term scaled by a_aff^2 / a_aff always: 1.131 / 1.041
   512 instances: fraction to the boundary 0.9 / 0.95 / 0.98 / 0.99: mean x 1.18 / 1.10 / 1.04 / 1.02, per-step maximum 12.9 / 12.3 / 12.1 / 12.4
   (baseline 12.15); centring with sigma >= 0.6 / 1 after a step shorter than 0.5 / 0.3: mean x 1.00-1.01, per-step maximum 11.9-12.2.
+  constraint_everywhere (128 x 100): baseline 6.66 it. / per-step max 11.35; affine exit cost 0.965; skip a>=.95 0.933 (max 11.57); skip a>=.9
+  0.919 (max 12.57); no 2nd-order term 1.40; ftb .999 0.964.   7-DoF N=40 (64 x 60): baseline 6.70 / 10.27; 0.968; 0.949 (10.50); 0.930 (11.05);
+  1.44; 0.975.
 -> a conditional corrector saves at most 4.7 % and costs robustness; without the second-order term +44 % iterations; the per-step
    maximum (what a launch lasts: spikes from collision rows that come active one stage after the other) does not respond to the
    step-length or centring rules."""
