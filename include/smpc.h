@@ -121,8 +121,10 @@ typedef struct {
                                 * constants of the QP: a violated one makes the QP infeasible and the instance reports
                                 * SMPC_STATUS_QP_FAILURE (the iterate is still returned, as acados does) */
     int32_t qp_stall_iters;    /* > 0: the IPM gives up (SMPC_STATUS_QP_FAILURE, the iterate is still returned) after this many
-                                * CONSECUTIVE stalled iterations: step length below 1/2 AND the complementarity not halved
-                                * either (an iterate that meets the exit test is never a stall).  0 = off: an infeasible QP then runs
+                                * CONSECUTIVE stalled iterations -- step length below 1/2 AND the complementarity not halved
+                                * either (an iterate that meets the exit test is never a stall) -- or after 7/6 of that many in
+                                * total (round 5: 24 -> 28; infeasible QPs whose complementarity falls in bursts reset the run
+                                * and took up to 52 iterations, now 31, with no feasible QP more given up).  0 = off: an infeasible QP then runs
                                 * until its step length underflows (40-90 iterations: what RealReceding's +-1e-3 tubes,
                                 * controller.py:531-532, produce in about 1 % of its solves).  A stall is not a proof of
                                 * infeasibility -- a feasible, degenerate QP can crawl for 20 iterations before it converges

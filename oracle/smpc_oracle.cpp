@@ -802,7 +802,7 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
     };
 
     double mu = mu_now();
-    int stall = 0;
+    int stall = 0, stall_total = 0;
     for (it = 0; it < o.max_iter; it++) {
         if (mu <= o.tol && rho * R0 <= o.tol_res) { status = 0; break; }
         if (!factorize()) { status = 4; break; }
@@ -860,8 +860,13 @@ int qp_ipm(std::vector<Stage>& S, int N, int nx, int nu, double dt, const double
         mu = mu_now();
         /* a stalled iteration: a short step that did not halve the complementarity either (a degenerate but feasible QP
          * crawls with short steps while mu still falls); an iterate that meets the exit test is never reported as stalled */
-        stall = (alpha < 0.5 && !(mu < 0.5 * mu_before)) ? stall + 1 : 0;
-        if (o.stall_iters > 0 && stall >= o.stall_iters && !(mu <= o.tol && rho * R0 <= o.tol_res)) { status = 5; it++; break; }
+        const bool stalled = alpha < 0.5 && !(mu < 0.5 * mu_before);
+        stall = stalled ? stall + 1 : 0;
+        stall_total += stalled ? 1 : 0;
+        /* ... stall_iters in a row, or 7/6 of that in total (round 5: an infeasible QP whose complementarity falls in bursts resets
+         * the run now and then and took up to 52 iterations where most give up after 27; with the cap on the total: 31) */
+        if (o.stall_iters > 0 && (stall >= o.stall_iters || stall_total >= o.stall_iters + (o.stall_iters + 5) / 6) &&
+            !(mu <= o.tol && rho * R0 <= o.tol_res)) { status = 5; it++; break; }
         if (std::getenv("SMPC_ORACLE_TRACE"))
             std::fprintf(stderr, "it %3d a_aff %.3e sigma %.3e alpha %.3e mu %.3e rho*R0 %.3e  blocked by stage %d row %d (tl %.2e ll %.2e tu %.2e lu %.2e)\n",
                          it, a_aff, sigma, alpha, mu, rho * R0, blk_k, blk_r, S[blk_k].tl[blk_r], S[blk_k].ll[blk_r], S[blk_k].tu[blk_r], S[blk_k].lu[blk_r]);

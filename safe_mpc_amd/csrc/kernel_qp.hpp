@@ -1511,8 +1511,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         if (!(mu == mu)) { st_code = 4; pending = false; break; }
         // a stalled iteration: a short step that did not halve the complementarity either (a degenerate but feasible QP
         // crawls with short steps while mu still falls); an iterate that meets the exit test is never reported as stalled
-        stall = (alpha < 0.5 && !(mu < 0.5 * mu_before)) ? stall + 1 : 0;
-        if (stall_max > 0 && stall >= stall_max && !(mu <= tol && rho_lin * R0 <= tol_r)) { st_code = 5; it++; break; }    // (the step just computed is still applied)
+        // ... stall_max of them in a row, or 7/6 of that in total (an infeasible QP whose complementarity falls in bursts resets the run
+        // now and then).  Both counts in one register: the run in the low half, the total in the high half.
+        {
+            const bool stalled = alpha < 0.5 && !(mu < 0.5 * mu_before);
+            stall = stalled ? stall + 0x10001 : (stall & ~0xffff);
+        }
+        if (stall_max > 0 && ((stall & 0xffff) >= stall_max || (stall >> 16) >= stall_max + (stall_max + 5) / 6) &&
+            !(mu <= tol && rho_lin * R0 <= tol_r)) { st_code = 5; it++; break; }    // (the step just computed is still applied)
     }
     if (it == max_iter && st_code == 2 && mu <= tol && rho_lin * R0 <= tol_r) st_code = 0;
 
