@@ -129,7 +129,7 @@ typedef struct {
                                 * controller.py:531-532, produce in about 1 % of its solves).  A stall is not a proof of
                                 * infeasibility -- a feasible, degenerate QP can crawl for 20 iterations before it converges
                                 * (tests/golden/c4_degenerate_start.npz) -- hence an option with a generous default where it is
-                                * switched on (24 for 'real_receding', problem.py) and none elsewhere */
+                                * switched on (24 for 'real_receding' and for the backup OCP, problem.py) and none elsewhere */
     int32_t reserved_i0;
     double dt;                 /* config.yaml:7 */
     double Q, R;               /* config.yaml:35,39 */

@@ -261,7 +261,10 @@ class OcpProblem:
         d.qp_max_iter = params.qp_max_iter
         d.qp_tol, d.qp_mu0 = float(getattr(params, 'qp_tol', 1e-8)), 1.0
         # stall exit of the IPM (include/smpc.h): on for RealReceding, whose tubes make ~1 % of its QPs infeasible
-        d.qp_stall_iters = int(getattr(params, 'qp_stall_iters', 24 if controller == 'real_receding' else 0))
+        # the stall exit (include/smpc.h) is on where infeasible QPs are part of normal operation: RealReceding's tubes, and the backup
+        # OCP (terminal zero velocity from the viable state of an aborting instance: in RealReceding's loop 27 of 29 such solves
+        # are infeasible and used to run 34 iterations on average, 52 at worst, until the step length underflowed; feasible ones take 5)
+        d.qp_stall_iters = int(getattr(params, 'qp_stall_iters', 24 if controller in ('real_receding', 'backup') else 0))
         d.qp_tol_res = float(getattr(params, 'qp_tol_res', 0.0))     # 0: same as qp_tol
         self.desc = d
 
