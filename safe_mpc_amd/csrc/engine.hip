@@ -98,6 +98,9 @@ struct smpc_handle {
     int pol_B = 0;
     float last_ms[4] = {0, 0, 0, 0};
     long mlp_rows_whole = 0;    // > 0 (a worker of smpc_rollout_batch): network rows of the WHOLE call, which selects the GEMM kernel
+    long mlp_rows_hint = 0;     // > 0 (smpc_policy_step of the receding policies): the rows EXPECTED to be live in a compacted list -- one or
+                                // two nodes per instance, where the list's capacity is every node -- which selects the network kernel
+                                // (the count itself is only known on the device; any kernel is correct for any count)
     char err[256] = "";
 };
 
@@ -254,7 +257,8 @@ template <int NQ> int run_mlp(smpc_handle* h, int M, int mode, int N, const doub
     // Few rows (the terminal row: M = B): the whole pass as ONE kernel, activations in LDS / registers (kernels_mlp.hpp).  The
     // choice follows the rows of the whole call (mlp_rows_whole), like the tiled kernel's below.
     {
-        const long rows_all = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128 : (long)Mp;
+        const long rows_all = h->mlp_rows_whole > 0 ? (h->mlp_rows_whole + 127) / 128 * 128
+                                                    : (h->mlp_rows_hint > 0 && mode == 3 ? (h->mlp_rows_hint + 127) / 128 * 128 : (long)Mp);
         static const bool no_fused = getenv("SMPC_MLP_UNFUSED") != nullptr;     // (A/B knob)
         static const long fused_max = [] { const char* e = getenv("SMPC_MLP_FUSED_MAX"); return e ? atol(e) : 8192L; }();   // (A/B knob)
         if (!no_fused && rows_all < fused_max && H == MLPF_H && L == 4 && (!backward || (d_p && d_ev))) {
@@ -1242,9 +1246,12 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
     }
     HIPCHK(h, hipGetLastError());
     h->d_active = stepping;
+    // (the receding policies carry the row at node r and at the end node, and test nodes r + 2 .. N afterwards -- in steady state one or
+    //  two per instance: their compacted lists are short, whatever their capacity)
+    h->mlp_rows_hint = receding ? 2L * B : 0L;
     DISPATCH_NQ(h, (launch_solve<NQ_>(h, B, x, st->x_guess, st->u_guess, st->p, st->x_temp, st->u_temp, st->status, st->qp_iter)));
     h->d_active = nullptr;
-    if (rc) return rc;
+    if (rc) { h->mlp_rows_hint = 0; return rc; }
     if (kind != SMPC_POLICY_NAIVE) {
         // checkStateConstraints(x_temp) (+ checkSafeConstraints(x_temp) on every node for the receding policies)
         const int coll = par->collision_first_node ? 1 : N + 1;
@@ -1256,9 +1263,12 @@ int smpc_policy_step(smpc_handle* h, int B, const smpc_policy_params* par, const
                                h->d_nn_idx, h->d_nn_cnt);
         }
         if ((rc = check_nodes_dev(h, B, N + 1, st->x_temp, par->tol_x, coll, par->alpha, par->tol_safe, d_ok, receding ? d_safe : nullptr,
-                                  receding, true)))
+                                  receding, true))) {
+            h->mlp_rows_hint = 0;
             return rc;
+        }
     }
+    h->mlp_rows_hint = 0;
     hipLaunchKernelGGL(k_policy_post, dim3((B + 63) / 64), dim3(64), 0, s, B, N, nx, kind, par->abort_flag, stepping, st->status,
                        d_ok, d_safe, st->x_guess, st->fails, st->current_step, st->r, st->x_viable, d_acc, d_act, abort_out, any_abort,
                        (receding && kind != SMPC_POLICY_NAIVE) ? h->d_nn_cnt : (int32_t*)nullptr);
