@@ -110,14 +110,15 @@ def roofline_of_launches(alg_bytes, ipm_ms, traffic_bytes_per_instance_iteration
             'note': 'per sub-batch launch INSIDE the closed loop (the streams share the chip): algorithmic bytes / HIP-event duration'}
 
 
-def build_problem():
+def build_problem(N=None, controller=None):
     from safe_mpc_amd.parser import Parameters
     from safe_mpc_amd.problem import OcpProblem
     from safe_mpc_amd.safe_set import SafeSetNet
+    N = HORIZON if N is None else N
     par = Parameters({}, 'z1')
-    par.nq, par.n_dof_safe_set, par.N = 6, 6, HORIZON
+    par.nq, par.n_dof_safe_set, par.N = 6, 6, N
     par.net_size = [12, 256, 1]
-    prob = OcpProblem(par, CONTROLLER, 'ext', N=HORIZON)
+    prob = OcpProblem(par, controller or CONTROLLER, 'ext', N=N)
     net = SafeSetNet.from_params(par, prob.x_min, prob.x_max)
     prob.set_normalisation(net.mean, net.std)
     return par, prob, net
@@ -203,6 +204,64 @@ def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=10.0, latency_solves=160):
             'sample': f'{done} instance-solves drawn cyclically from {len(x0)} C1 instances in the closed-loop state the GPU leg ended '
                       f'in (same x, shifted guess, p), OpenMP over instances, {dt:.1f} s; then {len(lat)} single-instance solves on one '
                       f'thread; oracle/smpc_oracle.cpp -O3 (dual-number derivatives, dense stage algebra), a CPU restatement -- not acados'}
+
+
+def cpu_baseline_latency(prob, net, states):
+    """The one-thread, one-instance leg of `cpu_baseline` on a given list of (x, x_guess, u_guess, p) states (numpy, B = 1)."""
+    from oracle.oracle import Oracle, build, set_num_threads
+    build()
+    o = Oracle(prob, (net.weights, net.biases))
+    set_num_threads(1)
+    lat = []
+    for x, xg, ug, p in states:
+        t1 = time.perf_counter()
+        o.solve_batch(x, xg, ug, p)
+        lat.append(time.perf_counter() - t1)
+    lat = np.array(lat) * 1e3
+    return {'p50_ms': float(np.quantile(lat, 0.5)), 'p99_ms': float(np.quantile(lat, 0.99)), 'mean_ms': float(lat.mean()),
+            'solves': int(len(lat))}
+
+
+def small_batch_latency(N=HORIZON, batches=(1,), n_steps=200, device=0, keep_states=None):
+    """Per-solve latency of a SMALL batch over an n_steps closed loop of controller 'st' (the statistic the reference prints for
+    its one-instance loop: quantiles of the solver time per step, scripts/mpc.py:239,300-303; budget dt = 5 ms, config.yaml:7).
+    Device-resident inputs, wall clock around `solve` + sync (launch latency included).  GPU only; the CPU port's one-thread
+    figure on the same kind of state is `cpu_baseline.latency_1thread_ms`."""
+    import torch
+    from safe_mpc_amd.solver import BatchedOcpSolver
+    dev = torch.device('cuda', device)
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device=dev)
+    par, prob, net = build_problem(N=N, controller='st')
+    rows = []
+    for B in batches:
+        sv = BatchedOcpSolver(prob, net, device=device)
+        x0 = initial_states(sv, prob, B, 3)
+        xg = np.repeat(x0[:, None, :], N + 1, axis=1)
+        ug = np.zeros((B, N, prob.nu))
+        p = np.zeros((B, N + 1, 5))
+        p[:, :, :3], p[:, :, 3], p[:, :, 4] = prob.ee_ref, par.alpha, 1.0
+        x, xg, ug, p = t(x0), t(xg), t(ug), t(p)
+        lat, its = [], []
+        for k in range(n_steps + 5):
+            if keep_states is not None and B == 1:
+                keep_states.append([a.cpu().numpy().copy() for a in (x, xg, ug, p)])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            xo, uo, st, it = sv.solve(x, xg, ug, p)
+            sv.sync()
+            dt_ = time.perf_counter() - t0
+            if k >= 5:
+                lat.append(dt_)
+                its.append(float(it.double().mean().item()))
+            xg, ug, ua = sv.provide_control((st == 0).to(torch.int32), xo, uo, xg, ug)
+            x, _ = sv.plant_step(x, ua)
+            xg = sv.guess_correction(xg, ug)
+            sv.sync()
+        lat = np.array(lat) * 1e3
+        rows.append({'N': N, 'B': B, 'p50_ms': float(np.quantile(lat, 0.5)), 'p99_ms': float(np.quantile(lat, 0.99)),
+                     'mean_ms': float(lat.mean()), 'mean_ipm_iterations': float(np.mean(its)), 'solves': int(len(lat))})
+        sv.close()
+    return rows
 
 
 def launch_children(args):
