@@ -200,6 +200,17 @@ int smpc_set_mlp_activation(smpc_handle* h, int act);
  * re-creating; N <= SMPC_MAX_N */
 int smpc_set_horizon(smpc_handle* h, int N);
 
+/* Which form of the QP solve a handle launches -- the engine's counterpart of the reference's choice of QP back-end
+ * (`ocp.solver_options.qp_solver`, controller.py:100-101: partial- or full-condensing HPIPM; `qp_solver_cond_N`, controller.py:209).
+ * Same algorithm and the same result to rounding either way; only the mapping onto the GPU differs:
+ *   SMPC_QP_AUTO (default)  by batch size: the latency form for small batches, the throughput form otherwise
+ *   SMPC_QP_THROUGHPUT      k_qp_ipm: one wavefront per pair of instances
+ *   SMPC_QP_LATENCY         k_qp_ipm_wg: one workgroup per instance, stage-parallel row work, recursions through LDS
+ *                           (falls back to the throughput form when a horizon's factor blocks do not fit one CU's LDS)
+ * (added in round 6; ABI version unchanged: no existing entry point or structure changed) */
+enum { SMPC_QP_AUTO = -1, SMPC_QP_THROUGHPUT = 0, SMPC_QP_LATENCY = 1 };
+int smpc_set_qp_mode(smpc_handle* h, int mode);
+
 /* replaces ocp_solver.constraints_set(k,'lbx'/'ubx',v) for k >= 1 (controller.py:531-536).  lo/hi are [N+1][nx]
  * shared by all instances, or NULL to restore the descriptor's bounds. */
 int smpc_set_stage_bounds(smpc_handle* h, const double* lo, const double* hi);

@@ -19,7 +19,7 @@ SYMBOLS = ['smpc_create', 'smpc_destroy', 'smpc_abi_version', 'smpc_last_error',
            'smpc_provide_control', 'smpc_check_trajectory', 'smpc_plant_step', 'smpc_rollout_batch', 'smpc_sync', 'smpc_stream',
            'smpc_enable_timing', 'smpc_get_timing', 'smpc_get_qp_timing', 'smpc_get_qp_wave_stats', 'smpc_policy_step', 'smpc_loop_pre',
            'smpc_loop_post', 'smpc_loop_apply_backup', 'smpc_loop_classify_aborts', 'smpc_get_timing_history',
-           'smpc_accumulate_stats', 'smpc_set_mlp_activation']
+           'smpc_accumulate_stats', 'smpc_set_mlp_activation', 'smpc_set_qp_mode']
 
 
 class EngineError(RuntimeError):
@@ -103,5 +103,6 @@ def lib():
     L.smpc_get_timing_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.smpc_accumulate_stats.argtypes = [vp, C.c_int, dp, dp, dp]
     L.smpc_set_mlp_activation.argtypes = [vp, C.c_int]
+    L.smpc_set_qp_mode.argtypes = [vp, C.c_int]
     _lib = L
     return L

@@ -10,6 +10,7 @@
 
 #include "../../include/smpc.h"
 #include "kernel_qp.hpp"
+#include "kernel_qp_wg.hpp"
 #include "kernel_build.hpp"
 #include "kernels_callers.hpp"
 #include "kernels_policy.hpp"
@@ -49,6 +50,9 @@ struct smpc_handle {
     bool ev_new_order[64] = {};   // per slot of the event ring: the solve ran MLP -> stage builder (ev1, ev2 swap their meaning)
     double* d_ws = nullptr;
     size_t ws_bytes = 0;
+    int qp_mode = -2;             // smpc_set_qp_mode: SMPC_QP_AUTO / _THROUGHPUT / _LATENCY; -2 = not set (the process default, SMPC_QP_WG)
+    double* d_hrec = nullptr;     // k_qp_ipm_wg only: the stages' P-independent blocks, [B][N+1][HRecLayout::SIZE] (allocated on first use)
+    size_t hrec_doubles = 0;
     int32_t *d_order = nullptr, *d_last_it = nullptr;  // longest-first dispatch order from the previous call's iterations
     int order_B = 0;                                   // batch size d_last_it is valid for (0 = none yet)
     int32_t* d_ord_hist = nullptr;                     // [256] histogram of d_last_it (k_qp_ipm) | [256] bin cursors | ticket (k_order_by_iters)
@@ -473,6 +477,61 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
     return SMPC_OK;
 }
 
+// k_qp_ipm_wg (kernel_qp_wg.hpp), the latency form of the interior-point solve -- one workgroup per instance: -1 (default) chosen by
+// batch size, 0 never, 1 whenever its LDS fits (SMPC_QP_WG; A/B runs and the parity tests).  Below qp_wg_max_batch instances the
+// chip has wavefront slots to spare and a launch lasts as long as ONE instance's iterations; above it k_qp_ipm's two instances per
+// wavefront use the chip better (measured: DESIGN.md section 4c).
+#ifndef QP_WG_MAX_BATCH
+#define QP_WG_MAX_BATCH 256
+#endif
+static int qp_wg_mode() {
+    static const int v = [] { const char* e = getenv("SMPC_QP_WG"); return e ? atoi(e) : -1; }();
+    return v;
+}
+static int qp_wg_max_batch() {
+    static const int v = [] { const char* e = getenv("SMPC_QP_WG_MAX_BATCH"); return e ? atoi(e) : QP_WG_MAX_BATCH; }();
+    return v;
+}
+constexpr size_t QP_WG_LDS_LIMIT = 160 * 1024 - 512;     // one CU's LDS less the kernel's static tables
+
+template <int NQ>
+int launch_qp_wg(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, double* xo, double* uo, int32_t* st,
+                 int32_t* it) {
+    const size_t need = (size_t)B * (h->N + 1) * HRecLayout<NQ>::SIZE;
+    if (need > h->hrec_doubles) {
+        int rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if ((rc = dev_alloc(h, &h->d_hrec, need))) return rc;
+        h->hrec_doubles = need;
+    }
+    const size_t lds = (size_t)WgLds<NQ>(h->N, h->desc.n_rows, QP_WG_NHW).total * sizeof(double);
+#define SMPC_WG_LAUNCH(MR_)                                                                                                        \
+    do {                                                                                                                           \
+        static size_t attr_set = 0;                                                                                                \
+        if (lds > attr_set) {                                                                                                      \
+            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qp_ipm_wg<NQ, MR_, QP_WG_NHW>),                         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
+            attr_set = lds;                                                                                                        \
+        }                                                                                                                          \
+        hipLaunchKernelGGL((k_qp_ipm_wg<NQ, MR_, QP_WG_NHW>), dim3(B), dim3(32 * QP_WG_NHW), lds, h->stream, h->d_desc, B, h->N, x0, xg, \
+                           ug, h->d_ws, h->d_hrec, xo, uo, st, it, h->d_last_it, h->d_active, h->d_ord_hist);                      \
+    } while (0)
+    switch (h->desc.n_rows) {
+    case 6: SMPC_WG_LAUNCH(6); break;
+    case 4: SMPC_WG_LAUNCH(4); break;
+    default: SMPC_WG_LAUNCH(-1); break;
+    }
+#undef SMPC_WG_LAUNCH
+    return SMPC_OK;
+}
+
+template <int NQ> bool qp_wg_wanted(const smpc_handle* h, int B) {
+    const int mode = h->qp_mode >= -1 ? h->qp_mode : qp_wg_mode();
+    if (mode == 0) return false;
+    if ((size_t)WgLds<NQ>(h->N, h->desc.n_rows, QP_WG_NHW).total * sizeof(double) > QP_WG_LDS_LIMIT) return false;
+    return mode > 0 || B <= qp_wg_max_batch();
+}
+
 template <int NQ>
 int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, const double* p,
                  double* xo, double* uo, int32_t* st, int32_t* it) {
@@ -495,8 +554,9 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
     }
     if ((rc = launch_stage_records<NQ>(h, B, x0, xg, ug, p, timed, path))) return rc;
+    const bool wg = qp_wg_wanted<NQ>(h, B);
     const int32_t* order = nullptr;
-    if (h->order_B == B && B > 1) {
+    if (h->order_B == B && B > 1 && !wg) {
         hipLaunchKernelGGL(k_order_by_iters, dim3((B + ORD_PER_BLOCK - 1) / ORD_PER_BLOCK), dim3(64), 0, h->stream, B, h->d_last_it,
                            h->d_order, h->d_ord_hist, h->d_ord_hist + 256, h->d_ord_hist + 512);
         order = h->d_order;
@@ -512,6 +572,9 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         wstat = h->d_wstat;
     }
     // non-temporal workspace accesses once this launch's workspace is well beyond the Infinity Cache (kernel_qp.hpp, k_qp_ipm)
+    if (wg) {
+        if ((rc = launch_qp_wg<NQ>(h, B, x0, xg, ug, xo, uo, st, it))) return rc;
+    } else {
     const bool nt = qp_nt_mode() < 0 ? ws_doubles_per_instance(h->desc, h->N) * sizeof(double) * (size_t)B >= qp_nt_threshold : qp_nt_mode() > 0;
 #define SMPC_QP_LAUNCH(MR_, NT_)                                                                                                   \
     hipLaunchKernelGGL((k_qp_ipm<NQ, MR_, NT_>), dim3((B + 1) / 2), dim3(64), qp_pad_lds(), h->stream, h->d_desc, B, h->N, x0, xg,  \
@@ -522,6 +585,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     default: SMPC_QP_LAUNCH(-1, false); break;      // (the runtime-row-count instantiation is not built twice)
     }
 #undef SMPC_QP_LAUNCH
+    }
     h->order_B = B;
     HIPCHK(h, hipGetLastError());
     if (timed) {
@@ -630,6 +694,7 @@ int rollout_workers(smpc_handle* h, int n) {
         if (k->N != h->N && (rc = smpc_set_horizon(k, h->N))) return fail(h, rc, "rollout worker: %s", k->err);
         k->nlayers = h->nlayers;
         k->act = h->act;
+        k->qp_mode = h->qp_mode;
         k->H = h->H;
         for (int l = 0; l <= SMPC_MAX_LAYERS; l++) k->dims[l] = h->dims[l];
         for (int l = 0; l < SMPC_MAX_LAYERS; l++) { k->d_Wfwd[l] = h->d_Wfwd[l]; k->d_Wbwd[l] = h->d_Wbwd[l]; k->d_bias[l] = h->d_bias[l]; }
@@ -714,7 +779,7 @@ void smpc_destroy(smpc_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-    void* ptrs[] = {h->d_desc, h->d_zl, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_nn, h->d_ws, h->d_order, h->d_last_it, h->d_ord_hist, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
+    void* ptrs[] = {h->d_desc, h->d_zl, h->d_lo, h->d_hi, h->d_lo_b, h->d_hi_b, h->d_ev, h->d_nn, h->d_ws, h->d_hrec, h->d_order, h->d_last_it, h->d_ord_hist, h->d_x0, h->d_xg, h->d_ug, h->d_p, h->d_xo, h->d_uo,
                     h->d_st, h->d_it, h->d_S, h->d_y, h->d_GS, h->d_dA, h->d_dB, h->d_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int l = 0; l < SMPC_MAX_LAYERS; l++) {
@@ -781,6 +846,14 @@ int smpc_set_mlp_activation(smpc_handle* h, int act) {
     if (act < SMPC_ACT_GELU_TANH || act > SMPC_ACT_SILU) return fail(h, SMPC_EINVAL, "unknown activation %d", act);
     h->act = act;
     for (smpc_handle* k : h->kids) k->act = act;
+    return SMPC_OK;
+}
+
+int smpc_set_qp_mode(smpc_handle* h, int mode) {
+    if (!h) return SMPC_EINVAL;
+    if (mode < SMPC_QP_AUTO || mode > SMPC_QP_LATENCY) return fail(h, SMPC_EINVAL, "qp mode %d (SMPC_QP_AUTO, _THROUGHPUT, _LATENCY)", mode);
+    h->qp_mode = mode;
+    for (smpc_handle* k : h->kids) k->qp_mode = mode;
     return SMPC_OK;
 }
 
@@ -1481,6 +1554,12 @@ extern "C" int smpc_debug_qp_profile(unsigned long long* out16) {
     unsigned long long zero[16] = {0};
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(smpc::g_qp_prof), sizeof(zero)) != hipSuccess) return -1;
     if (hipMemcpyToSymbol(HIP_SYMBOL(smpc::g_qp_prof), zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+extern "C" int smpc_debug_qp_wg_profile(unsigned long long* out16) {
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(smpc::g_wg_prof), sizeof(zero)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(smpc::g_wg_prof), zero, sizeof(zero)) != hipSuccess) return -1;
     return 0;
 }
 #endif

@@ -1,0 +1,856 @@
+// kernel_qp_wg.hpp -- k_qp_ipm_wg: the LATENCY form of the stage QP's interior-point solve (round 6).
+//
+// k_qp_ipm (kernel_qp.hpp) gives an instance half a wavefront and walks the horizon four times per iteration with it: whatever
+// the batch, an iteration of a lone instance costs 0.19 ms (Z1, N = 30), which is what the tail of every launch and a small batch
+// (one GPU's share of the 4096-instance headline on 8 GPUs: 512) pay.  About half of an iteration's work does not belong to the
+// recursions at all: it is the same for every stage and needs nothing of the stage before or after --
+//     rows: apply the step, barrier weights D, e;  H + C^T D C and g + C^T e of the stage;  c.z, ratio test, C^T e1, C^T e2.
+// Here ONE WORKGROUP (NHW half-wavefronts) owns an instance.  Per iteration:
+//   A  stage-parallel (half-wave h takes stages h, h + NHW, ...): rows + the stage's P-independent blocks -> "H record" (HBM / L2)
+//   B  wavefront 0: Riccati recursion  Lambda = Huu + B^T P B, G, Cholesky, [W | w], L^-1 -> factor blocks (LDS), P_k, p_k
+//   C  wavefront 0: predictor roll-out through the factors (LDS -> z in LDS)
+//   D  stage-parallel: c.z_aff, ratio test, e1 / e2, a1 = C^T e1, a2 = C^T e2 (LDS)
+//   E  wavefront 0: corrector costate (touches only LDS)
+//   F  wavefront 0: corrector roll-out
+//   G  stage-parallel: c.z+, ratio test, z+ -> workspace
+// with a workgroup barrier between phases and the step-length logic replicated on every lane.  The sequential phases keep the
+// factor blocks, the defects, a1 / a2 and the roll-out in LDS: no HBM round trip sits on their chains any more.
+// SAME algorithm, SAME workspace records (written by k_stage_build / k_qp_setup, QpLayout) and the same per-row arithmetic
+// (qp_row_dir / qp_row_coeff of kernel_qp.hpp) as k_qp_ipm; only the order of a few sums differs (the x-x block is assembled before
+// the recursion instead of inside the P update; complementarity sums are taken per half-wave, then over half-waves), so the two
+// kernels agree to rounding, iterate for iterate (tests/test_gpu_parity.py::test_qp_kernels_agree).
+// The engine picks per launch (engine.hip: qp_wg_max_batch): this form for small batches, k_qp_ipm for throughput.
+// Reference: controller.py:97-110, 136-167 (the QP HPIPM solves inside acados' RTI step).
+#pragma once
+#include "kernel_qp.hpp"
+
+namespace smpc {
+
+// P-independent blocks of one stage's KKT system, written by phase A and read by phase B of the same workgroup
+template <int NQ> struct HRecLayout {
+    static constexpr int NX = 2 * NQ, NZ = 3 * NQ;
+    static constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
+    static constexpr int oUU = 0;                              // upper triangle of Huu + (C^T D C)_uu, row by row
+    static constexpr int oUX = qp_even_c(NTRI_U);              // (C^T D C)_ux, NQ x NX row-major
+    static constexpr int oXX = oUX + NQ * NX;                  // upper triangle of the x-x block (order of the triX table: q-q corner first)
+    static constexpr int oGH = oXX + qp_even_c(NTRI_X);        // g + C^T e  [u | x]
+    static constexpr int SIZE = qp_al8(oGH + NZ);
+};
+
+template <int NQ> struct WgLds {
+    using LyT = QpLayout<NQ>;
+    static constexpr int NX = 2 * NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NWP = LyT::NWP;
+    int MRP, NRC, SCR_A, SCR_D, CST;
+    int o_fac, o_a12, o_scrd, o_z, o_wc, o_b, o_bf, o_seq;
+    int s_P0, s_P1, s_pv0, s_pv1, s_lam, s_G, s_WT, s_PB, s_H, s_rho, s_wv, s_red, s_flag;
+    int total;
+    // scratch of a half-wave in phase A: [image | D | E | TD | GD]; in phases D / G: [D | E | b, scalars | row-major general rows | dump]
+    int a_D, a_E, a_TD, a_GD;
+    int d_D, d_E, d_BS, d_CST, d_DUMP;
+    __host__ __device__ WgLds(int N, int MR, int NHW) {
+        MRP = qp_even_c(MR);
+        NRC = NQ + MR + 1;
+        const int IMG = NZ * NQP + NQ * MRP + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
+        a_D = qp_even_c(IMG); a_E = a_D + 32; a_TD = a_E + 32; a_GD = a_TD + NZ * NQP;
+        SCR_A = qp_even_c(a_GD + NQ * MRP);
+        CST = NRC * NZP;
+        d_D = 0; d_E = 32; d_BS = 64; d_CST = d_BS + qp_even_c(NX + 4); d_DUMP = d_CST + qp_even_c(CST);
+        SCR_D = d_DUMP + 2;
+        const int n1 = N + 1;
+        const int r0 = n1 * (NWP + 2 * NZP), ra = NHW * SCR_A;
+        o_fac = 0;
+        o_a12 = n1 * NWP;
+        o_scrd = r0 > ra ? r0 : ra;
+        o_z = o_scrd + NHW * SCR_D;
+        o_wc = o_z + n1 * NZP;
+        o_b = o_wc + n1 * NQP;
+        o_bf = o_b + n1 * NX;
+        o_seq = o_bf + qp_even_c(n1);
+        int s = o_seq;
+        s_P0 = s; s += NX * NX;
+        s_P1 = s; s += NX * NX;
+        s_pv0 = s; s += NX;
+        s_pv1 = s; s += NX;
+        s_lam = s; s += qp_even_c(NQ * NQ);
+        s_G = s; s += NQ * WS2;
+        s_WT = s; s += (NX + 1) * NQP;
+        s_PB = s; s += NX;
+        s_H = s; s += HRecLayout<NQ>::SIZE;
+        s_rho = s; s += NQP;
+        s_wv = s; s += NQP;
+        s_red = s; s += 4 * NHW;
+        s_flag = s; s += 2;
+        total = s;
+    }
+};
+
+#ifdef QP_PROFILE
+__device__ unsigned long long g_wg_prof[16];
+#define WGT(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define WGT(i) do { } while (0)
+#endif
+
+#ifndef QP_WG_NHW
+#define QP_WG_NHW 8
+#endif
+
+// One workgroup of NHW half-wavefronts per instance.  `list` (optional): the instances to solve (grid-stride over *list_n entries);
+// without it block b solves instance b.
+#ifndef QP_WG_WAVES_PER_EU
+#define QP_WG_WAVES_PER_EU 2
+#endif
+template <int NQ, int MRT, int NHW>
+__global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_WAVES_PER_EU, QP_WG_WAVES_PER_EU))) void k_qp_ipm_wg(
+    const smpc_problem_desc* __restrict__ D, int B, int N, const double* __restrict__ x0, const double* __restrict__ xg,
+    const double* __restrict__ ug, double* __restrict__ ws_all, double* __restrict__ hrec_all, double* __restrict__ x_out,
+    double* __restrict__ u_out, int32_t* __restrict__ status, int32_t* __restrict__ qp_iter, int32_t* __restrict__ last_iter,
+    const uint8_t* __restrict__ active, int32_t* __restrict__ it_hist) {
+    using LyT = QpLayout<NQ>;
+    using HR = HRecLayout<NQ>;
+    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, LC0 = LyT::LC0, KS = LyT::KS,
+                  NWP = LyT::NWP;
+    constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS, MRP_MAX = qp_even_c(MR_MAX), NRC_MAX = NQ + MR_MAX + 1;
+    constexpr int NTRI_U = HR::NTRI_U, NTRI_X = HR::NTRI_X;
+    constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4, IMG_PF = (IMG_MAX / 2 + 31) / 32;
+    constexpr int NF_MAX = NZ * NQP + NQ * MRP_MAX + NX + NX + 4, CST_PF = (NF_MAX / 2 + 31) / 32;
+    constexpr int NT = 32 * NHW;
+    static_assert(MRT < 0 || NX + NRC_MAX <= 32, "one lane per constraint row");
+    static_assert(KS <= 32, "one lane per column of [G | rho | I]");
+    static_assert(NTRI_U <= 32, "the q-q corner fits the first pass");
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    __shared__ unsigned char triUi[NTRI_U], triUj[NTRI_U], triXi[NTRI_X], triXj[NTRI_X];
+#ifdef QP_PROFILE
+    unsigned long long tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_readcyclecounter();
+#endif
+    const int tid = threadIdx.x, hl = tid & 31, hw = tid >> 5;
+    const bool seq = tid < 32;            // the lanes that run the sequential phases (half-wave 0)
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    if (active && !active[b]) {
+        if (tid == 0) {
+            status[b] = SMPC_STATUS_SUCCESS;
+            if (qp_iter) qp_iter[b] = 0;
+            if (last_iter) last_iter[b] = 0;
+            if (it_hist) atomicAdd(&it_hist[0], 1);
+        }
+        return;
+    }
+    const LyT Ly(MRT >= 0 ? MRT : D->n_rows);
+    const WgLds<NQ> Ls(N, Ly.MR, NHW);
+    const int MR = Ly.MR, MRP = Ly.MRP, NRC = Ly.NRC, NRT = Ly.NRT;
+    const int rT0 = NX, rC0 = NX + NQ, rNN = NX + NQ + MR;
+    double* const ws = ws_all + (size_t)b * Ly.per_instance(N);
+    double* const hrec = hrec_all + (size_t)b * (N + 1) * HR::SIZE;
+    const double dt = D->dt, cB = 0.5 * dt * dt;
+    const int img_n2 = Ly.nIMG >> 1, c_n2 = Ly.nF >> 1;
+
+    // index tables (as in k_qp_ipm)
+    for (int e = tid; e < NTRI_U; e += NT) {
+        int i = 0, rem = e;
+        while (rem >= NQ - i) { rem -= NQ - i; i++; }
+        triUi[e] = (unsigned char)i;
+        triUj[e] = (unsigned char)(i + rem);
+    }
+    for (int e = tid; e < NTRI_X; e += NT) {
+        int i = 0, j;
+        if (e < NTRI_U) {
+            int rem = e;
+            while (rem >= NQ - i) { rem -= NQ - i; i++; }
+            j = i + rem;
+        } else {
+            int rem = e - NTRI_U;
+            while (rem >= (i < NQ ? NQ : NX - i)) { rem -= (i < NQ ? NQ : NX - i); i++; }
+            j = (i < NQ ? NQ : i) + rem;
+        }
+        triXi[e] = (unsigned char)i;
+        triXj[e] = (unsigned char)j;
+    }
+
+    const double* xb0 = xg + (size_t)b * (N + 1) * NX;
+    const double* ub0 = ug + (size_t)b * N * NU;
+    // lane roles inside a half-wave (clamped: lanes past an array's end repeat its last entry)
+    const int hl_u = hl < NQ ? hl : NQ - 1;
+    const int hl_x = hl < NX ? hl : NX - 1;
+    const int hr = hl < NRT ? hl : NRT - 1;
+    const bool row_live = hl < NRT;
+    const int hl_c = hr >= NX ? hr - NX : 0;
+    const int hz = hl < NZ ? hl : NZ - 1;
+    const int hl_px = hz >= NU ? hz - NU : 0;
+    const int hc = hl < KS ? hl : KS - 1;
+    const bool soft_lane = (hr == rNN);
+    const int wbase = hc <= NX ? hc * NQ
+                               : ((hc < LC0 || hc - LC0 >= NQ) ? NWP - (LyT::LOFF + NQ * (NQ + 1) / 2) % 2
+                                                                : LyT::w_coff(hc - LC0) - (hc - LC0));
+
+    double* const sFac = dsm + Ls.o_fac;
+    double* const sA12 = dsm + Ls.o_a12;
+    double* const sZ = dsm + Ls.o_z;
+    double* const sWC = dsm + Ls.o_wc;
+    double* const sBk = dsm + Ls.o_b;
+    double* const sBf = dsm + Ls.o_bf;
+    double* const sLam = dsm + Ls.s_lam;
+    double* const sG = dsm + Ls.s_G;
+    double* const sWT = dsm + Ls.s_WT;
+    double* const sPB = dsm + Ls.s_PB;
+    double* const sH = dsm + Ls.s_H;
+    double* const sRho = dsm + Ls.s_rho;
+    double* const sWv = dsm + Ls.s_wv;
+    double* const sRed = dsm + Ls.s_red;
+    double* const sFlag = dsm + Ls.s_flag;
+
+    auto pdot = [&](const double* a, const double* bb, int n2) -> double {
+        const dbl2* a2 = reinterpret_cast<const dbl2*>(a);
+        const dbl2* b2 = reinterpret_cast<const dbl2*>(bb);
+        double s0 = 0.0, s1 = 0.0;
+        for (int h = 0; h < n2; h++) {
+            const dbl2 x = a2[h], y = b2[h];
+            s0 = fma(x.x, y.x, s0);
+            s1 = fma(x.y, y.y, s1);
+        }
+        return s0 + s1;
+    };
+    // max / sum / sum over the whole workgroup; every thread gets the result (fixed order: half-waves 0, 1, ...)
+    auto block_reduce = [&](double& vmax, double& s1, double& s2) {
+        vmax = half_max(vmax); s1 = half_sum(s1); s2 = half_sum(s2);
+        if (hl == 0) { sRed[4 * hw] = vmax; sRed[4 * hw + 1] = s1; sRed[4 * hw + 2] = s2; }
+        __syncthreads();
+        double m = sRed[0], a = sRed[1], c = sRed[2];
+#pragma unroll
+        for (int j = 1; j < NHW; j++) { m = fmax(m, sRed[4 * j]); a += sRed[4 * j + 1]; c += sRed[4 * j + 2]; }
+        vmax = m; s1 = a; s2 = c;
+        __syncthreads();
+    };
+
+    // where piece j of a stage's [Tt | Gt | gn | b | scalars] goes in the row-major scratch of the row phases (as in k_qp_ipm's
+    // forward sweeps: transposed on the way into LDS; pads go to a dump cell)
+    int cdst[CST_PF];
+    {
+        auto dst_of = [&](int e) -> int {
+            if (e < NZ * NQP) {
+                const int c = e / NQP, r = e - c * NQP;
+                return r < NQ ? Ls.d_CST + r * NZP + c : Ls.d_DUMP;
+            }
+            if (e < NZ * NQP + NQ * MRP) {
+                const int t = e - NZ * NQP, ix = t / max(MRP, 1), r = t - ix * MRP;
+                return r < MR ? Ls.d_CST + (NQ + r) * NZP + NU + ix : Ls.d_DUMP;
+            }
+            if (e < Ly.nJ) return Ls.d_CST + (NQ + MR) * NZP + NU + (e - NZ * NQP - NQ * MRP);
+            return Ls.d_BS + (e - Ly.nJ);      // the defect (NX) and the stage scalars (4)
+        };
+#pragma unroll
+        for (int j = 0; j < CST_PF; j++) {
+            const int e = 2 * min(hl + 32 * j, c_n2 - 1);
+            cdst[j] = dst_of(e) | (dst_of(e + 1) << 16);
+        }
+    }
+    {
+        // structural zeros of the row-major image (this scratch belongs to the row phases for the whole kernel)
+        double* scr = dsm + Ls.o_scrd + hw * Ls.SCR_D;
+        for (int el = hl; el < NRC * NZP; el += 32) scr[Ls.d_CST + el] = 0.0;
+    }
+
+    // ---- initial residual norm and complementarity from the setup partials ------------------------------------------------
+    double R0 = 0.0, mu;
+    int m_comp;
+    {
+        double ms = 0.0, cn = 0.0;
+        for (int k = hl; k <= N; k += 32) {
+            const double* pt = ws + (size_t)k * Ly.stride + Ly.oPART;
+            R0 = fmax(R0, pt[0]);
+            ms += pt[1];
+            cn += pt[2];
+        }
+        R0 = half_max(R0);
+        m_comp = (int)half_sum(cn);
+        if (m_comp == 0) m_comp = 1;
+        mu = half_sum(ms) / (double)m_comp;
+    }
+    const double inv_m = 1.0 / (double)m_comp;
+    const double dx0_reg = hl < NX ? x0[(size_t)b * NX + hl] - xb0[hl] : 0.0;
+
+    double rho_lin = 1.0, alpha = 0.0, sigmu = 0.0, corr_w = 1.0;
+    bool pending = false;
+    int it = 0, st_code = 2;
+    const double tol = D->qp_tol;
+    const double tol_r = D->qp_tol_res > 0.0 ? D->qp_tol_res : D->qp_tol;
+    const int max_iter = D->qp_max_iter;
+    const int stall_max = D->qp_stall_iters;
+    int stall = 0;
+    if (tid == 0) sFlag[0] = 0.0;
+    __syncthreads();
+    WGT(13);
+
+    for (it = 0; it < max_iter; it++) {
+        if (mu <= tol && rho_lin * R0 <= tol_r) { st_code = 0; break; }
+
+        // =============== phase A: rows + P-independent blocks of every stage ==============================================
+        double mu_new = 0.0;
+        {
+            double* const scr = dsm + hw * Ls.SCR_A;       // (over the factor blocks and a1 / a2 of the previous iteration: dead)
+            double* const sIMG = scr;
+            double* const sTT = sIMG + Ly.iTT;
+            double* const sGT = sIMG + Ly.iGT;
+            double* const sGN = sIMG + Ly.iGN;
+            double* const sHQQ = sIMG + Ly.iHQQ;
+            double* const sGZ = sIMG + Ly.iGZ;
+            double* const sB = sIMG + Ly.iB;
+            double* const sSC = sIMG + Ly.iSC;
+            double* const sD = scr + Ls.a_D;
+            double* const sE = scr + Ls.a_E;
+            double* const sTD = scr + Ls.a_TD;
+            double* const sGD = scr + Ls.a_GD;
+            for (int k = hw; k <= N; k += NHW) {
+                const bool last = (k == N);
+                double* w = ws + (size_t)k * Ly.stride;
+                double* hk = hrec + (size_t)k * HR::SIZE;
+                dbl2 img[IMG_PF];
+                {
+                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
+#pragma unroll
+                    for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
+                }
+                QpRow rs;
+                {
+                    const dbl2 r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr], r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr],
+                               r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
+                    rs.lo = r0.x; rs.hi = r0.y; rs.tl = r1.x; rs.tu = r1.y; rs.ll = r2.x; rs.lu = r2.y;
+                }
+                const double czar = w[Ly.oCZA + hr], cznr = w[Ly.oCZN + hr];
+                const dbl2 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
+                double zc = w[Ly.oZ + hz];
+                const double znc = w[Ly.oZN + hz];
+                {
+                    dbl2* d2 = reinterpret_cast<dbl2*>(sIMG);
+#pragma unroll
+                    for (int j = 0; j < IMG_PF; j++) d2[min(hl + 32 * j, img_n2 - 1)] = img[j];
+                }
+                const double wsoft = slb.x;
+                {
+                    const bool soft = soft_lane && wsoft >= 0.0;
+                    double rr_ = 0.0, s1_ = 0.0, s2_ = 0.0;
+                    const QpDir rd = qp_row_dir<false>(rs, soft, wsoft, cznr, sigmu, corr_w, czar, &rr_, &s1_, &s2_, nullptr, nullptr);
+                    rs.tl += alpha * rd.dtl; rs.ll += alpha * rd.dll;
+                    rs.tu += alpha * rd.dtu; rs.lu += alpha * rd.dlu;
+                    reinterpret_cast<dbl2*>(w + Ly.oR1)[hr] = dbl2{rs.tl, rs.tu};
+                    reinterpret_cast<dbl2*>(w + Ly.oR2)[hr] = dbl2{rs.ll, rs.lu};
+                    double Dr;
+                    sE[hr] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
+                    sD[hr] = Dr;
+                    mu_new += row_live ? qp_row_comp(rs, soft, wsoft) : 0.0;
+                }
+                zc += alpha * (znc - zc);
+                w[Ly.oZ + hz] = zc;
+                lds_fence();
+                // the defect and its flag stay in LDS for the recursions
+                if (hl < NX) sBk[k * NX + hl] = sB[hl];
+                if (hl == 0) sBf[k] = (!last && slb.y != 0.0) ? 1.0 : 0.0;
+                // rows scaled by their barrier weights
+                if constexpr (NQ % 2 == 0) {
+                    constexpr int TD_P = (NZ * NQP / 2 + 31) / 32, GD_P = (NQ * MRP_MAX / 2 + 31) / 32;
+                    const dbl2* tt2 = reinterpret_cast<const dbl2*>(sTT);
+                    const dbl2* gt2 = reinterpret_cast<const dbl2*>(sGT);
+                    dbl2 ta[TD_P], td[TD_P], ga[GD_P], gd[GD_P];
+#pragma unroll
+                    for (int t = 0; t < TD_P; t++) {
+                        const int e2 = min(hl + 32 * t, NZ * NQP / 2 - 1);
+                        ta[t] = tt2[e2];
+                        td[t] = reinterpret_cast<const dbl2*>(sD + rT0)[e2 % (NQP / 2)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < GD_P; t++) {
+                        const int e2 = max(min(hl + 32 * t, NQ * (MRP >> 1) - 1), 0);
+                        const int r2 = e2 % max(MRP >> 1, 1);
+                        ga[t] = gt2[e2];
+                        gd[t] = reinterpret_cast<const dbl2*>(sD + rC0)[r2];
+                        if (2 * r2 + 1 >= MR) gd[t].y = 0.0;
+                    }
+#pragma unroll
+                    for (int t = 0; t < TD_P; t++) reinterpret_cast<dbl2*>(sTD)[min(hl + 32 * t, NZ * NQP / 2 - 1)] = ta[t] * td[t];
+#pragma unroll
+                    for (int t = 0; t < GD_P; t++)
+                        if (MR > 0) reinterpret_cast<dbl2*>(sGD)[max(min(hl + 32 * t, NQ * (MRP >> 1) - 1), 0)] = ga[t] * gd[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < (NZ * NQP + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NZ * NQP - 1);
+                        const int r = el % NQP;
+                        sTD[el] = sTT[el] * sD[rT0 + (r < NQ ? r : 0)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < (NQ * MRP_MAX + 31) / 32; t++) {
+                        const int el = hl + 32 * t;
+                        if (el < NQ * MRP) {
+                            const int r = el % MRP;
+                            sGD[el] = sGT[el] * sD[rC0 + (r < MR ? r : 0)];
+                        }
+                    }
+                }
+                lds_fence();
+                // u-u triangle and u-x block of H + C^T D C (no torque rows at the end stage: the blocks are not used there)
+                if (!last) {
+#pragma unroll
+                    for (int t = 0; t < (NTRI_U + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NTRI_U - 1);
+                        const int i = triUi[el], j = triUj[el];
+                        double a = pdot(sTT + i * NQP, sTD + j * NQP, NQP / 2);
+                        a += i == j ? sSC[0] : 0.0;
+                        hk[HR::oUU + el] = a;
+                    }
+#pragma unroll
+                    for (int t = 0; t < (NQ * NX + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NQ * NX - 1);
+                        const int i = el / NX, jx = el - i * NX;
+                        hk[HR::oUX + el] = pdot(sTT + i * NQP, sTD + (NU + jx) * NQP, NQP / 2);
+                    }
+                }
+                // x-x triangle
+#pragma unroll
+                for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
+                    const int el = min(hl + 32 * t, NTRI_X - 1);
+                    const int ix = triXi[el], jx = triXj[el];
+                    const double dii = sD[ix], lmv = sSC[1], dnn = sD[rNN];
+                    double a = pdot(sTT + (NU + ix) * NQP, sTD + (NU + jx) * NQP, NQP / 2);
+                    a = fma(sGN[ix] * dnn, sGN[jx], a);
+                    if (32 * t < NTRI_U) {
+                        const int iq = min(ix, NQ - 1), jq = min(jx, NQ - 1);
+                        const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
+                        a += jx < NQ ? qq : 0.0;
+                    }
+                    a += ix == jx ? dii + (ix >= NQ ? lmv : 0.0) : 0.0;
+                    hk[HR::oXX + el] = a;
+                }
+                // gradient g + C^T e
+                {
+                    const int ix = hl_px, iq = min(hl_px, NQ - 1);
+                    const double g0 = sGZ[hz], eb = sE[ix], gn_i = sGN[ix], e_nn = sE[rNN];
+                    const double gnn = gn_i * e_nn;
+                    double tq = 0.0, cq = 0.0;
+                    if constexpr (NQ % 2 == 0) {
+                        tq = pdot(sTT + hz * NQP, sE + rT0, NQP / 2);
+                        cq = pdot(sGT + iq * MRP, sE + rC0, MRP >> 1);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < NQ; r++) tq = fma(sTT[hz * NQP + r], sE[rT0 + r], tq);
+                        for (int r = 0; r < MR; r++) cq = fma(sGT[iq * MRP + r], sE[rC0 + r], cq);
+                    }
+                    const double gh = g0 + tq + (hz >= NU ? eb + gnn + (ix < NQ ? cq : 0.0) : 0.0);
+                    hk[HR::oGH + hz] = gh;
+                }
+                lds_fence();      // (the next stage of this half-wave overwrites the scratch)
+            }
+        }
+        if (pending) {
+            double dummy_m = 0.0, dummy_s = 0.0;
+            block_reduce(dummy_m, mu_new, dummy_s);      // (ends with a barrier: phase A's stores are visible to wavefront 0)
+            mu = mu_new * inv_m;
+            pending = false;
+            if (!(mu == mu)) { st_code = 4; break; }
+        } else {
+            __syncthreads();
+        }
+        WGT(0);
+
+        // =============== phase B: Riccati recursion (half-wave 0) ==========================================================
+        if (seq) {
+            double *Pc = dsm + Ls.s_P0, *Pn = dsm + Ls.s_P1, *pvc = dsm + Ls.s_pv0, *pvn = dsm + Ls.s_pv1;
+            constexpr int HPF2 = (HR::SIZE / 2 + 31) / 32;
+            dbl2 hp[HPF2];
+            auto load_h = [&](int k) {
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(hrec + (size_t)k * HR::SIZE);
+#pragma unroll
+                for (int j = 0; j < HPF2; j++) hp[j] = s2[min(hl + 32 * j, HR::SIZE / 2 - 1)];
+            };
+            auto commit_h = [&]() {
+                dbl2* d2 = reinterpret_cast<dbl2*>(sH);
+#pragma unroll
+                for (int j = 0; j < HPF2; j++) d2[min(hl + 32 * j, HR::SIZE / 2 - 1)] = hp[j];
+            };
+            double Lr[NQ][NQ], Linv[NQ];
+            bool broke = false;
+            load_h(N);
+            commit_h();
+            load_h(N > 0 ? N - 1 : 0);
+            lds_fence();
+            // P_N = the x-x block, p_N = the x part of the gradient
+#pragma unroll
+            for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
+                const int el = min(hl + 32 * t, NTRI_X - 1);
+                const int ix = triXi[el], jx = triXj[el];
+                const double a = sH[HR::oXX + el];
+                Pc[ix * NX + jx] = a;
+                Pc[jx * NX + ix] = a;
+            }
+            if (hl < NX) pvc[hl] = sH[HR::oGH + NU + hl];
+            lds_fence();
+            for (int k = N - 1; k >= 0; k--) {
+                double* const fk = sFac + k * NWP;
+                commit_h();
+                load_h(k > 0 ? k - 1 : 0);
+                {
+                    const double a = sBf[k] != 0.0 ? pdot(Pc + hl_x * NX, sBk + k * NX, NX / 2) : 0.0;
+                    sPB[hl_x] = a;
+                }
+                lds_fence();
+                WGT(7);
+                // Lambda = Huu + B^T P B (triangle, mirrored), G = Hux + B^T P A, rho = gh_u + B^T (p + P b)
+#pragma unroll
+                for (int t = 0; t < (NTRI_U + 31) / 32; t++) {
+                    const int el = min(hl + 32 * t, NTRI_U - 1);
+                    const int i = triUi[el], j = triUj[el];
+                    double a = sH[HR::oUU + el];
+                    a += cB * cB * Pc[i * NX + j] + cB * dt * (Pc[i * NX + NQ + j] + Pc[(NQ + i) * NX + j]) + dt * dt * Pc[(NQ + i) * NX + NQ + j];
+                    sLam[i * NQ + j] = a;
+                    sLam[j * NQ + i] = a;
+                }
+#pragma unroll
+                for (int t = 0; t < (NQ * NX + 31) / 32; t++) {
+                    const int el = min(hl + 32 * t, NQ * NX - 1);
+                    const int i = el / NX, jx = el - i * NX;
+                    const bool right = jx >= NQ;
+                    const int jj = right ? jx - NQ : jx;
+                    double a = sH[HR::oUX + el];
+                    const double left = cB * Pc[i * NX + jj] + dt * Pc[(NQ + i) * NX + jj];
+                    a += right ? dt * left + cB * Pc[i * NX + jx] + dt * Pc[(NQ + i) * NX + jx] : left;
+                    sG[i * WS2 + jx] = a;
+                }
+                double ghx;
+                {
+                    const double gh = sH[HR::oGH + hz];
+                    const bool ctl = hz < NU;
+                    const double pb1 = sPB[ctl ? hz : hl_px], pb2 = sPB[ctl ? NQ + hz : (hl_px >= NQ ? hl_px - NQ : 0)];
+                    const double pv1 = pvc[hl_u], pv2 = pvc[NQ + hl_u];
+                    const double rho = gh + cB * (pv1 + pb1) + dt * (pv2 + pb2);
+                    if (hl < NU) sG[hl * WS2 + NX] = rho;
+                    ghx = gh;
+                }
+                lds_fence();
+                WGT(8);
+                // Cholesky of Lambda in registers (every lane), one column of [W | w | L^-1] per lane
+                {
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) {
+                        double dsum = sLam[j * NQ + j];
+#pragma unroll
+                        for (int t = 0; t < j; t++) dsum = fma(-Lr[j][t], Lr[j][t], dsum);
+                        broke = broke || !(dsum > 0.0);
+                        const double inv = fast_rsqrt(dsum);
+                        Linv[j] = inv;
+#pragma unroll
+                        for (int i = j + 1; i < NQ; i++) {
+                            double v = sLam[i * NQ + j];
+#pragma unroll
+                            for (int t = 0; t < j; t++) v = fma(-Lr[i][t], Lr[j][t], v);
+                            Lr[i][j] = v * inv;
+                        }
+                    }
+                    double col[NQ];
+                    const int cg = hc <= NX ? hc : NX;
+#pragma unroll
+                    for (int i = 0; i < NQ; i++) col[i] = hc <= NX ? sG[i * WS2 + cg] : (i == hc - LC0 ? 1.0 : 0.0);
+#pragma unroll
+                    for (int i = 0; i < NQ; i++) {
+                        double v = col[i];
+#pragma unroll
+                        for (int t = 0; t < i; t++) v = fma(-Lr[i][t], col[t], v);
+                        col[i] = v * Linv[i];
+                    }
+                    if (hc <= NX) {
+#pragma unroll
+                        for (int i = 0; i < NQ; i++) sWT[hc * NQP + i] = col[i];
+                        if (NQP > NQ) sWT[hc * NQP + NQ] = 0.0;
+                    }
+                    // (in this order: the zeros above a column's diagonal land on the tail of the column before it and are overwritten there by
+                    //  that column's later stores; the lanes between the two groups of columns hold nothing of the block)
+                    if (hc <= NX || (hc >= LC0 && hc - LC0 < NQ)) {
+#pragma unroll
+                        for (int i = 0; i < NQ; i++) fk[wbase + i] = col[i];
+                    }
+                }
+                lds_fence();
+                WGT(9);
+                if (k > 0) {
+                    // P_k = Hxx + A^T P A - W^T W,  p_k = gh_x + A^T (p + P b) - W^T w
+#pragma unroll
+                    for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
+                        const int el = min(hl + 32 * t, NTRI_X - 1);
+                        const int i = triXi[el], j = triXj[el];
+                        const int ii = i >= NQ ? i - NQ : i, jj = j >= NQ ? j - NQ : j;
+                        double a = sH[HR::oXX + el] - pdot(sWT + i * NQP, sWT + j * NQP, NQP / 2);
+                        const double cj = j >= NQ ? dt : 0.0, ci = i >= NQ ? dt : 0.0;
+                        a += Pc[i * NX + j] + cj * Pc[i * NX + jj] + ci * (Pc[ii * NX + j] + dt * Pc[ii * NX + jj]);
+                        Pn[i * NX + j] = a;
+                        Pn[j * NX + i] = a;
+                    }
+                    {
+                        const int i = hl_px, i2 = i >= NQ ? i - NQ : 0;
+                        const double q1 = pvc[i] + sPB[i], q2 = pvc[i2] + sPB[i2];
+                        double v = ghx + q1 + (i >= NQ ? dt * q2 : 0.0);
+                        v -= pdot(sWT + i * NQP, sWT + NX * NQP, NQP / 2);
+                        if (hl >= NU && hl < NZ) pvn[i] = v;
+                    }
+                    lds_fence();
+                    double* t1 = Pc; Pc = Pn; Pn = t1;
+                    double* t2 = pvc; pvc = pvn; pvn = t2;
+                }
+                WGT(10);
+            }
+            if (half_max(broke ? 1.0 : 0.0) > 0.0 && hl == 0) sFlag[0] = 1.0;
+        }
+        __syncthreads();
+        WGT(1);
+        if (sFlag[0] != 0.0) { st_code = 4; pending = false; break; }
+
+        // roll-out through the factor blocks: z_k = [u_k | x_k] for every stage (half-wave 0)
+        auto rollout = [&](auto corr_tag) {
+            constexpr bool CORR = decltype(corr_tag)::value;
+            if (hl < NX) sZ[NU + hl] = dx0_reg;
+            lds_fence();
+            const int iu = hl_x < NQ ? hl_x : hl_x - NQ;
+            const int lb_u = LyT::w_coff(iu) - iu;
+            for (int k = 0; k < N; k++) {
+                const double* fk = sFac + k * NWP;
+                double* zk = sZ + k * NZP;
+                {
+                    const double* wr_ = fk + hl_u;
+                    double a = wr_[NX * NQ] + (CORR ? sWC[k * NQP + hl_u] : 0.0), a_v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) {
+                        a = fma(wr_[j * NQ], zk[NU + j], a);
+                        a_v = fma(wr_[(NQ + j) * NQ], zk[NU + NQ + j], a_v);
+                    }
+                    a += a_v;
+                    if (hl < NQ) sRho[hl] = a;
+                }
+                lds_fence();
+                {
+                    // u_i = -(L^-T rho)_i on the lanes i and NQ + i; x+ = A x + B u + b
+                    double a = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) a = fma(iu <= j ? fk[lb_u + j] : 0.0, sRho[j], a);
+                    const double u = -a;
+                    if (hl < NQ) zk[hl] = u;
+                    if (hl < NX) {
+                        const double bi = sBk[k * NX + hl];
+                        zk[NZP + NU + hl] = hl < NQ ? zk[NU + hl] + dt * zk[NU + NQ + hl] + cB * u + bi : zk[NU + hl] + dt * u + bi;
+                    }
+                }
+                lds_fence();
+            }
+            if (hl < NQ) sZ[N * NZP + hl] = 0.0;      // no control at the end stage
+        };
+        // rows of every stage for the roll-out in sZ (stage-parallel): ratio test, sums; predictor: c.z_aff, a1 / a2; corrector: c.z+, z+
+        auto rows_phase = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
+            constexpr bool CORR = decltype(corr_tag)::value;
+            double rr = 0.0, S1 = 0.0, S2 = 0.0;
+            double* const scr = dsm + Ls.o_scrd + hw * Ls.SCR_D;
+            double* const sD = scr + Ls.d_D;
+            double* const sE = scr + Ls.d_E;
+            double* const sBS = scr + Ls.d_BS;
+            double* const sCst = scr + Ls.d_CST;
+            for (int k = hw; k <= N; k += NHW) {
+                double* w = ws + (size_t)k * Ly.stride;
+                const double* zk = sZ + k * NZP;
+                dbl2 Cs[CST_PF];
+                {
+                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
+#pragma unroll
+                    for (int j = 0; j < CST_PF; j++) Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
+                }
+                const dbl2 r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr], r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr],
+                           r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
+                double cza = 0.0;
+                if (CORR) cza = w[Ly.oCZA + hr];
+#pragma unroll
+                for (int j = 0; j < CST_PF; j++) {
+                    scr[cdst[j] & 0xffff] = Cs[j].x;
+                    scr[cdst[j] >> 16] = Cs[j].y;
+                }
+                lds_fence();
+                {
+                    const double* cr = sCst + hl_c * NZP;
+                    double a = 0.0, a_q = 0.0, a_v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NQ; c++) {
+                        a = fma(cr[c], zk[c], a);
+                        a_q = fma(cr[NU + c], zk[NU + c], a_q);
+                        a_v = fma(cr[NU + NQ + c], zk[NU + NQ + c], a_v);
+                    }
+                    a += a_q + a_v;
+                    const double cz = hr < NX ? zk[NU + hl_x] : a;
+                    const QpRow rs{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+                    const double wsoft = sBS[NX + 2];
+                    const bool soft = soft_lane && wsoft >= 0.0;
+                    double s1_ = 0.0, s2_ = 0.0;
+                    if (!CORR) {
+                        double e1, e2;
+                        qp_row_dir<true>(rs, soft, wsoft, cz, 0.0, 0.0, cz, &rr, &s1_, &s2_, &e1, &e2);
+                        w[Ly.oCZA + hr] = cz;
+                        sD[hr] = e1;
+                        sE[hr] = e2;
+                    } else {
+                        qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, cza, &rr, &s1_, &s2_, nullptr, nullptr);
+                        w[Ly.oCZN + hr] = cz;
+                        w[Ly.oZN + hz] = zk[hz];
+                    }
+                    S1 += row_live ? s1_ : 0.0;
+                    S2 += row_live ? s2_ : 0.0;
+                }
+                if (!CORR) {
+                    lds_fence();
+                    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+                    {
+                        constexpr int RH = (NRC_MAX + 1) / 2;
+                        double cc[RH], d1[RH], d2[RH];
+#pragma unroll
+                        for (int hh = 0; hh < 2; hh++) {
+#pragma unroll
+                            for (int r = 0; r < RH; r++) {
+                                const int rr_ = min(min(hh * RH + r, NRC_MAX - 1), NRC - 1);
+                                cc[r] = sCst[rr_ * NZP + hz];
+                                d1[r] = sD[NX + rr_];
+                                d2[r] = sE[NX + rr_];
+                            }
+#pragma unroll
+                            for (int r = 0; r < RH; r++) {
+                                const bool on = hh * RH + r < NRC && hh * RH + r < NRC_MAX;
+                                if (hh == 0) { a1 = on ? fma(cc[r], d1[r], a1) : a1; a2 = on ? fma(cc[r], d2[r], a2) : a2; }
+                                else { b1 = on ? fma(cc[r], d1[r], b1) : b1; b2 = on ? fma(cc[r], d2[r], b2) : b2; }
+                            }
+                        }
+                    }
+                    a1 += b1;
+                    a2 += b2;
+                    if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
+                    if (hl < NZ) reinterpret_cast<dbl2*>(sA12 + k * 2 * NZP)[hz] = dbl2{a1, a2};
+                }
+                lds_fence();
+            }
+            block_reduce(rr, S1, S2);
+            *rr_out = rr; *S1_out = S1; *S2_out = S2;
+        };
+
+        // =============== phases C, D: predictor ============================================================================
+        if (seq) rollout(std::false_type{});
+        __syncthreads();
+        WGT(2);
+        double rr_aff, S1, S2;
+        rows_phase(std::false_type{}, &rr_aff, &S1, &S2);
+        WGT(3);
+        const double a_aff = rr_aff > 1.0 ? 1.0 / rr_aff : 1.0;
+        const double mu_aff = (mu * (double)m_comp + a_aff * S1 + a_aff * a_aff * S2) * inv_m;
+        double sigma = mu_aff / mu;
+        sigma = fmin(sigma * sigma * sigma, 0.3);
+        sigmu = sigma * mu;
+        corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
+
+        // =============== phase E: corrector costate (half-wave 0) ===========================================================
+        if (seq) {
+            double *pvc = dsm + Ls.s_pv0, *pvn = dsm + Ls.s_pv1;
+            const int ip1 = hl < NU ? hl : hl_px;
+            const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
+            {
+                const dbl2 a12 = reinterpret_cast<const dbl2*>(sA12 + N * 2 * NZP)[hz];
+                const double gh = sigmu * a12.x + corr_w * a12.y;
+                if (hz >= NU && hl < NZ) pvc[hz - NU] = gh;
+            }
+            lds_fence();
+            for (int k = N - 1; k >= 0; k--) {
+                const double* fk = sFac + k * NWP;
+                const dbl2 a12 = reinterpret_cast<const dbl2*>(sA12 + k * 2 * NZP)[hz];
+                const double gh = sigmu * a12.x + corr_w * a12.y;
+                const double q1 = pvc[ip1], q2 = pvc[ip2];
+                if (hl < NU) sRho[hl] = gh + cB * q1 + dt * q2;
+                lds_fence();
+                {
+                    double v = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) v = fma(j <= hl_u ? fk[LyT::w_coff(j) - j + hl_u] : 0.0, sRho[j], v);
+                    if (hl < NQ) { sWv[hl] = v; sWC[k * NQP + hl] = v; }
+                }
+                lds_fence();
+                if (k > 0) {
+                    if (hz >= NU && hl < NZ) {
+                        double v = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
+#pragma unroll
+                        for (int t = 0; t < NQ; t++) v = fma(-fk[hl_px * NQ + t], sWv[t], v);
+                        pvn[hl_px] = v;
+                    }
+                    lds_fence();
+                    double* t2 = pvc; pvc = pvn; pvn = t2;
+                }
+            }
+        }
+        __syncthreads();
+        WGT(4);
+        // =============== phases F, G: corrector =============================================================================
+        if (seq) rollout(std::true_type{});
+        __syncthreads();
+        WGT(5);
+        double rr_max, S1c, S2c;
+        rows_phase(std::true_type{}, &rr_max, &S1c, &S2c);
+        WGT(6);
+        const double a_max = rr_max > 0.0 ? 1.0 / rr_max : 1e300;
+        const double tau_k = a_max >= 0.99 ? fmin(0.9999, fmax(QP_FTB, 1.0 - mu)) : QP_FTB;
+        alpha = fmin(1.0, tau_k * a_max);
+        if (!(alpha == alpha)) { st_code = 4; break; }
+        if (alpha < QP_ALPHA_MIN) { st_code = 3; break; }
+        pending = true;
+        rho_lin *= (1.0 - alpha);
+        const double mu_before = mu;
+        mu = (mu * (double)m_comp + alpha * S1c + alpha * alpha * S2c) * inv_m;
+        if (!(mu == mu)) { st_code = 4; pending = false; break; }
+        {
+            const bool stalled = alpha < 0.5 && !(mu < 0.5 * mu_before);
+            stall = stalled ? stall + 0x10001 : (stall & ~0xffff);
+        }
+        if (stall_max > 0 && ((stall & 0xffff) >= stall_max || (stall >> 16) >= stall_max + (stall_max + 5) / 6) &&
+            !(mu <= tol && rho_lin * R0 <= tol_r)) { st_code = 5; it++; break; }
+    }
+    if (it == max_iter && st_code == 2 && mu <= tol && rho_lin * R0 <= tol_r) st_code = 0;
+
+    // ---- full SQP step, applying the last IPM step if it is still pending (stage-parallel) --------------------------------
+    __syncthreads();
+    double bad = 0.0;
+    const double a_fin = pending ? alpha : 0.0;
+    for (int idx = tid; idx < (N + 1) * NZ; idx += NT) {
+        const int k = idx / NZ, c = idx - k * NZ;
+        const double* w = ws + (size_t)k * Ly.stride;
+        const double zz = w[Ly.oZ + c], zzn = w[Ly.oZN + c];
+        if (c < NU) {
+            if (k < N) {
+                const double v = ub0[(size_t)k * NU + c] + zz + a_fin * (zzn - zz);
+                u_out[((size_t)b * N + k) * NU + c] = v;
+                bad = !(v == v) ? 1.0 : bad;
+            }
+        } else {
+            const double v = xb0[(size_t)k * NX + c - NU] + zz + a_fin * (zzn - zz);
+            x_out[((size_t)b * (N + 1) + k) * NX + c - NU] = v;
+            bad = !(v == v) ? 1.0 : bad;
+        }
+    }
+    {
+        double d1 = 0.0, d2 = 0.0;
+        block_reduce(bad, d1, d2);
+    }
+    WGT(12);
+#ifdef QP_PROFILE
+    if (tid == 0) {
+        for (int i = 0; i < 14; i++) atomicAdd(&g_wg_prof[i], tacc[i]);
+        atomicAdd(&g_wg_prof[14], 1ull);
+        atomicAdd(&g_wg_prof[15], (unsigned long long)it);
+    }
+#endif
+    if (tid == 0) {
+        int stc = (st_code == 0 || st_code == 2) ? SMPC_STATUS_SUCCESS : SMPC_STATUS_QP_FAILURE;
+        if (ws[Ly.oPART + 3] != 0.0) stc = SMPC_STATUS_QP_FAILURE;
+        if (bad > 0.0 && stc == SMPC_STATUS_SUCCESS) stc = SMPC_STATUS_NAN;
+        status[b] = stc;
+        if (qp_iter) qp_iter[b] = it;
+        if (last_iter) last_iter[b] = it;
+        if (it_hist) atomicAdd(&it_hist[min(it, 255)], 1);
+    }
+}
+
+}  // namespace smpc

@@ -90,6 +90,13 @@ class BatchedOcpSolver:
         self._chk(self.L.smpc_set_mlp_activation(self.h, SafeSetNet.ACT_CODES[act]))      # SMPC_ACT_* (parser.py:95-102)
         self.net = net
 
+    QP_MODES = {'auto': -1, 'throughput': 0, 'latency': 1}
+
+    def set_qp_mode(self, mode):
+        """Which form of the QP solve this handle launches (smpc_set_qp_mode): 'auto' (by batch size), 'throughput' (k_qp_ipm, a
+        wavefront per two instances) or 'latency' (k_qp_ipm_wg, a workgroup per instance).  Same result to rounding."""
+        self._chk(self.L.smpc_set_qp_mode(self.h, self.QP_MODES[mode] if isinstance(mode, str) else int(mode)))
+
     def set_horizon(self, N):
         self._chk(self.L.smpc_set_horizon(self.h, int(N)))
         self.N = int(N)

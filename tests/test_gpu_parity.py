@@ -18,9 +18,24 @@ from conftest import constant_guess, make_problem, sample_instances
 pytestmark = pytest.mark.gpu
 
 
+_QP_MODE = [None]      # None: the engine's own choice by batch size; 'throughput' / 'latency': forced (fixture qp_mode)
+
+
 def _solver(prob, net):
     from safe_mpc_amd.solver import BatchedOcpSolver
-    return BatchedOcpSolver(prob, net)
+    s = BatchedOcpSolver(prob, net)
+    if _QP_MODE[0] is not None:
+        s.set_qp_mode(_QP_MODE[0])
+    return s
+
+
+@pytest.fixture(params=['throughput', 'latency'])
+def qp_mode(request):
+    """Both forms of the interior-point solve (smpc_set_qp_mode): k_qp_ipm, a wavefront per two instances, and k_qp_ipm_wg, a
+    workgroup per instance.  Tests that take this fixture run once with each; the others run with the engine's own choice."""
+    _QP_MODE[0] = request.param
+    yield request.param
+    _QP_MODE[0] = None
 
 
 def _oracle(prob, net):
@@ -56,7 +71,7 @@ def test_eval_nodes_parity(controller, cost):
                                                    ('st', 'ext', 30, 1e-4), ('htwa', 'ext', 15, 1e-4),
                                                    ('constraint_everywhere', 'ext', 10, 1e-4),
                                                    ('receding', 'ext', 12, 1e-4), ('backup', 'ext', 25, 5e-4)])
-def test_rti_solve_parity(controller, cost, N, tol):
+def test_rti_solve_parity(controller, cost, N, tol, qp_mode):
     par, prob, net = make_problem(controller, cost, N=N)
     s, o = _solver(prob, net), _oracle(prob, net)
     B = 32
@@ -208,7 +223,7 @@ def test_policy_layer_and_scripts_on_engine(tmp_path):
         assert np.nanmax(np.abs(gpu['x'][both] - cpu['x'][both])) < 1e-4
 
 
-def test_instance_bounds_parity():
+def test_instance_bounds_parity(qp_mode):
     """smpc_set_instance_bounds: per-instance state tubes (RealReceding) agree with the oracle and clear again."""
     par, prob, net = make_problem('real_receding', N=10)
     s, o = _solver(prob, net), _oracle(prob, net)
@@ -232,7 +247,7 @@ def test_instance_bounds_parity():
     assert np.array_equal(ua1, ua0)
 
 
-def test_stall_exit_parity_on_infeasible_tubes():
+def test_stall_exit_parity_on_infeasible_tubes(qp_mode):
     """qp_stall_iters -- engine and oracle give up on the same infeasible RealReceding QPs at the same
     iteration (QP failure, iterate still returned), and the option leaves feasible solves alone."""
     from test_oracle_qp import _unreachable_tube
@@ -255,7 +270,7 @@ def test_stall_exit_parity_on_infeasible_tubes():
 
 
 @pytest.mark.parametrize('nq,B,drop_rows', [(6, 1, 0), (6, 33, 0), (5, 17, 0), (6, 9, 2), (6, 12, 6), (6, 11, -6), (7, 6, -4)])
-def test_kernel_instantiations_and_odd_batches(nq, B, drop_rows):
+def test_kernel_instantiations_and_odd_batches(nq, B, drop_rows, qp_mode):
     """k_qp_ipm pairs two instances per wavefront: odd batches leave a lone half-wave; nq = 5 (the reference's default
     n_dofs, config.yaml:10) and a row count other than the specialised 6 take other template instantiations.  The extremes:
     no collision rows at all, SMPC_MAX_ROWS = 12 of them, and (nq = 7, 10 rows) the stage that fills all 32 row lanes."""
@@ -463,8 +478,60 @@ def test_stage_builder_records_equal_oracle_qp(case):
                 assert abs(r0[nx + nq + MR, 0] - lo[nx + nq + MR]) < 2e-4 * (1 + abs(lo[nx + nq + MR]))
 
 
+@pytest.mark.parametrize('case', ['st', 'constraint_everywhere', 'receding', 'zerovel_nls', 'fr7', 'nq5_rows4'])
+def test_qp_kernels_agree(case):
+    """k_qp_ipm_wg (a workgroup per instance: stage-parallel row work, recursions through LDS; round 6) against k_qp_ipm (a wavefront
+    per two instances) on the SAME handle-built stage records: same algorithm and per-row arithmetic, a few sums in another order.
+    Over a ten-step closed loop driven by the throughput kernel's result: statuses equal at every solve, iteration counts equal but
+    for the odd instance whose exit test is decided by rounding (<= 1 apart), every control within 2e-6 (1 + |u|) where the counts
+    are equal -- the tolerance of two IPMs walking the same path from rounding-different starts (the first, cold solve agrees to
+    1e-8; from the second step on the QPs have flat directions, DESIGN.md section 5, and rounding-level differences of the Newton
+    systems show up at 1e-7); a different count means one more IPM step, i.e. the solution tolerance."""
+    from conftest import make_problem_fr7
+    nq = 6
+    if case == 'fr7':
+        par, prob, net = make_problem_fr7(N=40)
+        nq = 7
+    elif case == 'zerovel_nls':
+        par, prob, net = make_problem('zerovel', 'nls', N=20)
+    elif case == 'nq5_rows4':
+        par, prob, net = make_problem('st', 'ext', N=12, nq=5)
+        prob.desc.n_rows -= 2
+        nq = 5
+    else:
+        par, prob, net = make_problem(case, 'ext', N=30)
+    N = prob.N
+    a, b = _solver(prob, net), _solver(prob, net)
+    a.set_qp_mode('throughput'); b.set_qp_mode('latency')
+    B = 96 if case != 'fr7' else 40
+    x = sample_instances(prob, B, seed=21, vel_scale=0.1)
+    xg, ug, p = constant_guess(prob, x)
+    if case == 'receding':
+        p[:, 1:N, 4] = -1.0
+        p[np.arange(B), 1 + np.arange(B) % (N - 1), 4] = 1.0
+    worst, differ = 0.0, 0
+    for step in range(10):
+        xa, ua, sa, ia = a.solve(x, xg, ug, p)
+        xb, ub, sb, ib = b.solve(x, xg, ug, p)
+        assert np.array_equal(sa, sb), step
+        d = np.abs(ia.astype(int) - ib.astype(int))
+        assert d.max() <= 1, (step, ia, ib)
+        differ += int((d > 0).sum())
+        same = (d == 0) & (sa == 0)
+        if same.any():
+            err = np.abs(ua[same] - ub[same]).max() / (1 + np.abs(ua[same]).max())
+            worst = max(worst, err)
+            assert err < (1e-7 if step == 0 else 2e-6), (step, err)
+            assert np.abs(xa[same] - xb[same]).max() < 2e-6
+        xg, ug, uapp = a.provide_control((sa == 0).astype(np.int32), xa, ua, xg, ug)
+        x, _ = a.plant_step(x, uapp)
+        xg = a.guess_correction(xg, ug)
+    assert differ <= max(2, B // 10), differ
+    print(f'[qp kernels, {case}] worst control gap {worst:.1e}, {differ} solves with iteration counts one apart')
+
+
 @pytest.mark.parametrize('N', [1, 2, 3, 63])
-def test_horizon_extremes(N):
+def test_horizon_extremes(N, qp_mode):
     """Shortest horizons (the unrolled / look-ahead loops of the QP kernel degenerate) and SMPC_MAX_N."""
     par, prob, net = make_problem('st', 'ext', N=N)
     s, o = _solver(prob, net), _oracle(prob, net)
@@ -489,7 +556,7 @@ def test_empty_batch_is_a_no_op():
 
 
 @pytest.mark.parametrize('controller', ['st', 'constraint_everywhere'])
-def test_closed_loop_tracks_oracle(controller):
+def test_closed_loop_tracks_oracle(controller, qp_mode):
     """Eight closed-loop RTI steps (guessCorrection -> solve -> provideControl -> plant) on the engine and on the oracle from the
     same start: same statuses every step, states within 1e-5 at the end (the fp32 network is the only non-FP64 piece)."""
     par, prob, net = make_problem(controller, 'ext', N=20)
@@ -664,7 +731,7 @@ def test_eval_nodes_device_path_large_batch_stream_order():
         del junk
 
 
-def test_rows_at_node0_status_parity():
+def test_rows_at_node0_status_parity(qp_mode):
     """controller.py:77-79: a start inside the collision band reports QP failure, engine and oracle alike."""
     par, prob, net = make_problem('naive', 'ext', N=8)
     s, o = _solver(prob, net), _oracle(prob, net)
@@ -1047,7 +1114,7 @@ def test_policy_entry_points_reject_misuse():
 
 
 @pytest.mark.parametrize('controller', ['st', 'constraint_everywhere'])
-def test_engine_against_independent_dense_qp_solver_at_full_horizon(controller):
+def test_engine_against_independent_dense_qp_solver_at_full_horizon(controller, qp_mode):
     """The engine's RTI step at the bench's size (Z1, N = 30) against tests/qp_ref.py -- a condensed dense QP solved by a plain
     log-barrier Newton method with numpy.linalg: no Riccati recursion, no Mehrotra corrector, different variables.  The QP data
     come from the oracle's linearisation (which the engine matches to 1e-14, test_eval_nodes_parity); what is pinned here is
@@ -1074,7 +1141,7 @@ def test_engine_against_independent_dense_qp_solver_at_full_horizon(controller):
 
 
 @pytest.mark.parametrize('case', ['st', 'constraint_everywhere', 'receding', 'fr7'])
-def test_late_closed_loop_qps_against_independent_dense_solver(case):
+def test_late_closed_loop_qps_against_independent_dense_solver(case, qp_mode):
     """the solver-independent cross-check on QPs taken from the RUNNING closed loop of the engine
     itself, not only on cold starts -- Z1 'st' and 'constraint_everywhere' (steps 40, 100), 'receding' with its switched running
     row (the row on at ONE running node that recedes with the step, controller.py:452-469), and BASELINE config 4's 7-DoF / N = 40
@@ -1099,7 +1166,7 @@ def test_late_closed_loop_qps_against_independent_dense_solver(case):
           f'gap default, gap tight, objective): {[tuple(float(f"{v:.3g}") for v in r) for r in rows]}')
 
 
-def test_engine_against_independent_dense_qp_solver_c4():
+def test_engine_against_independent_dense_qp_solver_c4(qp_mode):
     """The same for BASELINE config 4 (7-DoF, N = 40, safe-set row on every node)."""
     from conftest import make_problem_fr7
     from qp_ref import condense, solve_condensed
