@@ -26,23 +26,32 @@
 
 namespace smpc {
 
-// P-independent blocks of one stage's KKT system, written by phase A and read by phase B of the same workgroup
+// P-independent blocks of one stage's KKT system, written by phase A and read by phase B of the same workgroup.  Laid out for the
+// reader: wavefront 0 takes every element straight into the register of the lane that uses it (no LDS staging on the recursion's
+// chain) -- element e of [triangle of Huu | Hux row-major] by lane e mod 64, the x-x block as full rows of 16 so that lane (g, c) of the
+// f64 MFMA's result layout finds rows g, g + 4, ... of column c, the gradient by the lane of its variable.
 template <int NQ> struct HRecLayout {
     static constexpr int NX = 2 * NQ, NZ = 3 * NQ;
     static constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
-    static constexpr int oUU = 0;                              // upper triangle of Huu + (C^T D C)_uu, row by row
-    static constexpr int oUX = qp_even_c(NTRI_U);              // (C^T D C)_ux, NQ x NX row-major
-    static constexpr int oXX = oUX + NQ * NX;                  // upper triangle of the x-x block (order of the triX table: q-q corner first)
-    static constexpr int oGH = oXX + qp_even_c(NTRI_X);        // g + C^T e  [u | x]
+    static constexpr int NE = NTRI_U + NQ * NX;                // elements of [triangle of Huu + (C^T D C)_uu | (C^T D C)_ux]
+    static constexpr int oA = 0;                               // ... element e at oA + e
+    static constexpr int oXX = 128;                            // x-x block, full, row i at oXX + 16 i
+    static constexpr int oGH = oXX + 16 * NX;                  // g + C^T e  [u | x]
     static constexpr int SIZE = qp_al8(oGH + NZ);
+    static_assert(NE <= 128 && NX + 1 <= 16, "two elements per lane; [W | w] fits one 16 x 16 tile");
 };
 
 template <int NQ> struct WgLds {
     using LyT = QpLayout<NQ>;
-    static constexpr int NX = 2 * NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, NWP = LyT::NWP;
+    static constexpr int NX = 2 * NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2;
+    // factor block of a stage as this kernel keeps it in LDS: NQ rows of [W | w | pad | L^-1], row-major -- the column solve's lanes
+    // store with one base address and immediate offsets, the roll-outs read row i of [W | w] and the corrector row i of L^-1 as whole
+    // 16-byte pieces, and L^-1 carries its zeros (no masks in the recursions)
+    static constexpr int LCOL = NX + 2, FS = qp_even_c(NX + 2 + NQ), NFW = NQ * FS;
+    static constexpr int NZS = NZP + 2;        // roll-out record of a stage: [u | x | two cells that absorb the stores of idle lanes]
     int MRP, NRC, SCR_A, SCR_D, CST;
     int o_fac, o_a12, o_scrd, o_z, o_wc, o_b, o_bf, o_seq;
-    int s_P0, s_P1, s_pv0, s_pv1, s_lam, s_G, s_WT, s_PB, s_H, s_rho, s_wv, s_red, s_flag;
+    int s_P, s_pv, s_lam, s_G, s_R, s_V, s_red, s_flag;
     int total;
     // scratch of a half-wave in phase A: [image | D | E | TD | GD]; in phases D / G: [D | E | b, scalars | row-major general rows | dump]
     int a_D, a_E, a_TD, a_GD;
@@ -57,27 +66,22 @@ template <int NQ> struct WgLds {
         d_D = 0; d_E = 32; d_BS = 64; d_CST = d_BS + qp_even_c(NX + 4); d_DUMP = d_CST + qp_even_c(CST);
         SCR_D = d_DUMP + 2;
         const int n1 = N + 1;
-        const int r0 = n1 * (NWP + 2 * NZP), ra = NHW * SCR_A;
+        const int r0 = n1 * (NFW + 2 * NZP), ra = NHW * SCR_A;
         o_fac = 0;
-        o_a12 = n1 * NWP;
+        o_a12 = n1 * NFW;
         o_scrd = r0 > ra ? r0 : ra;
         o_z = o_scrd + NHW * SCR_D;
-        o_wc = o_z + n1 * NZP;
+        o_wc = o_z + (n1 + 1) * NZS;
         o_b = o_wc + n1 * NQP;
         o_bf = o_b + n1 * NX;
         o_seq = o_bf + qp_even_c(n1);
         int s = o_seq;
-        s_P0 = s; s += NX * NX;
-        s_P1 = s; s += NX * NX;
-        s_pv0 = s; s += NX;
-        s_pv1 = s; s += NX;
+        s_P = s; s += NX * NX;
+        s_pv = s; s += NX + 2;               // (+ a cell for the stores of idle lanes)
         s_lam = s; s += qp_even_c(NQ * NQ);
         s_G = s; s += NQ * WS2;
-        s_WT = s; s += (NX + 1) * NQP;
-        s_PB = s; s += NX;
-        s_H = s; s += HRecLayout<NQ>::SIZE;
-        s_rho = s; s += NQP;
-        s_wv = s; s += NQP;
+        s_R = s; s += NQP + 2;               // rho of a stage (hand-off inside the roll-outs / the corrector's recursion) + dump
+        s_V = s; s += NQP + 2;               // L^-1 rho of the corrector's recursion + dump
         s_red = s; s += 4 * NHW;
         s_flag = s; s += 2;
         total = s;
@@ -95,10 +99,52 @@ __device__ unsigned long long g_wg_prof[16];
 #define QP_WG_NHW 8
 #endif
 
+typedef double v4d __attribute__((ext_vector_type(4)));
+// "These N values are needed HERE": one empty asm that lists them all -- the compiler then issues every load behind them before this
+// point and waits once (kernel_qp.hpp: hold_rows2 / hold_rows4; left alone it sinks each LDS read next to its use, and a lone wavefront
+// pays a round trip through LDS per read: profiles/r06_wg_isa_before_hold.txt)
+template <int N> __device__ __forceinline__ void hold_n(double (&a)[N]) {
+    static_assert(N >= 1 && N <= 28, "one asm statement takes at most 30 operands");
+    if constexpr (N == 1) asm volatile("" : "+v"(a[0]));
+    else if constexpr (N == 2) asm volatile("" : "+v"(a[0]), "+v"(a[1]));
+    else if constexpr (N == 3) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]));
+    else if constexpr (N == 4) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    else if constexpr (N == 5) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]));
+    else if constexpr (N == 6) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+    else if constexpr (N == 7) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]));
+    else if constexpr (N == 8) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+    else if constexpr (N == 9) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
+    else if constexpr (N == 10) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]));
+    else if constexpr (N == 11) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]));
+    else if constexpr (N == 12) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]));
+    else if constexpr (N == 13) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]));
+    else if constexpr (N == 14) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]));
+    else if constexpr (N == 15) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]));
+    else if constexpr (N == 16) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+    else if constexpr (N == 17) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]));
+    else if constexpr (N == 18) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]));
+    else if constexpr (N == 19) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]));
+    else if constexpr (N == 20) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]));
+    else if constexpr (N == 21) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]));
+    else if constexpr (N == 22) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]));
+    else if constexpr (N == 23) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]));
+    else if constexpr (N == 24) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]));
+    else if constexpr (N == 25) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]), "+v"(a[24]));
+    else if constexpr (N == 26) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]), "+v"(a[24]), "+v"(a[25]));
+    else if constexpr (N == 27) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]), "+v"(a[24]), "+v"(a[25]), "+v"(a[26]));
+    else if constexpr (N == 28) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]), "+v"(a[24]), "+v"(a[25]), "+v"(a[26]), "+v"(a[27]));
+}
+// a double of lane `lane` for every lane (v_readlane_b32 x 2; the index is a constant): a six-vector that lives on six lanes reaches the
+// whole wavefront in a dozen scalar moves, without a round trip through LDS
+__device__ __forceinline__ double rdlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // One workgroup of NHW half-wavefronts per instance.  `list` (optional): the instances to solve (grid-stride over *list_n entries);
 // without it block b solves instance b.
 #ifndef QP_WG_WAVES_PER_EU
-#define QP_WG_WAVES_PER_EU 2
+#define QP_WG_WAVES_PER_EU 1
 #endif
 template <int NQ, int MRT, int NHW>
 __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_WAVES_PER_EU, QP_WG_WAVES_PER_EU))) void k_qp_ipm_wg(
@@ -108,8 +154,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     const uint8_t* __restrict__ active, int32_t* __restrict__ it_hist) {
     using LyT = QpLayout<NQ>;
     using HR = HRecLayout<NQ>;
-    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, LC0 = LyT::LC0, KS = LyT::KS,
-                  NWP = LyT::NWP;
+    constexpr int NX = 2 * NQ, NU = NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2, LC0 = LyT::LC0, KS = LyT::KS;
     constexpr int MR_MAX = MRT >= 0 ? MRT : SMPC_MAX_ROWS, MRP_MAX = qp_even_c(MR_MAX), NRC_MAX = NQ + MR_MAX + 1;
     constexpr int NTRI_U = HR::NTRI_U, NTRI_X = HR::NTRI_X;
     constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4, IMG_PF = (IMG_MAX / 2 + 31) / 32;
@@ -125,7 +170,9 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     unsigned long long tprev = __builtin_readcyclecounter();
 #endif
     const int tid = threadIdx.x, hl = tid & 31, hw = tid >> 5;
-    const bool seq = tid < 32;            // the lanes that run the sequential phases (half-wave 0)
+    const bool seq = tid < 64;            // wavefront 0 runs the sequential phases (its upper half mirrors the lower one wherever a
+                                          // phase is written for 32 lanes: same values to the same addresses)
+    const int ln = tid & 63, lg = ln >> 4, lc = ln & 15;      // lane of the wavefront; (group, column) in the f64 MFMA's result layout
     const int b = blockIdx.x;
     if (b >= B) return;
     if (active && !active[b]) {
@@ -180,9 +227,6 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     const int hl_px = hz >= NU ? hz - NU : 0;
     const int hc = hl < KS ? hl : KS - 1;
     const bool soft_lane = (hr == rNN);
-    const int wbase = hc <= NX ? hc * NQ
-                               : ((hc < LC0 || hc - LC0 >= NQ) ? NWP - (LyT::LOFF + NQ * (NQ + 1) / 2) % 2
-                                                                : LyT::w_coff(hc - LC0) - (hc - LC0));
 
     double* const sFac = dsm + Ls.o_fac;
     double* const sA12 = dsm + Ls.o_a12;
@@ -192,11 +236,6 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     double* const sBf = dsm + Ls.o_bf;
     double* const sLam = dsm + Ls.s_lam;
     double* const sG = dsm + Ls.s_G;
-    double* const sWT = dsm + Ls.s_WT;
-    double* const sPB = dsm + Ls.s_PB;
-    double* const sH = dsm + Ls.s_H;
-    double* const sRho = dsm + Ls.s_rho;
-    double* const sWv = dsm + Ls.s_wv;
     double* const sRed = dsm + Ls.s_red;
     double* const sFlag = dsm + Ls.s_flag;
 
@@ -250,6 +289,68 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         double* scr = dsm + Ls.o_scrd + hw * Ls.SCR_D;
         for (int el = hl; el < NRC * NZP; el += 32) scr[Ls.d_CST + el] = 0.0;
     }
+
+    // ---- per-lane constants of the sequential phases (wavefront 0; cheap, so every wavefront computes them) -------------------
+    // One wavefront alone issues an instruction every ~5 clocks whatever it is (scripts/lat_probe.hip, profiles/r06_lat_probe.txt):
+    // the recursions are bound by their instruction COUNT.  So every lane-dependent LDS address is formed once, here.
+    constexpr int XR = (NX + 3) / 4;          // rows of the x-x tile per lane: lane (g, c) owns rows g + 4 r of column c
+    constexpr int XR_W = NX / 4;              // ... and row NX (W^T w) sits in register XR_W of the lanes of group NX % 4
+    constexpr int FS = WgLds<NQ>::FS, LCOL = WgLds<NQ>::LCOL, NFW = WgLds<NQ>::NFW, NZS = WgLds<NQ>::NZS;
+    double* const sP = dsm + Ls.s_P;
+    double* const sPv = dsm + Ls.s_pv;
+    double* const sR = dsm + Ls.s_R;
+    double* const sV = dsm + Ls.s_V;
+    // [Lambda | G]: element e = ln + 64 t is  H_e + sum of four entries of P_{k+1} with fixed coefficients (B^T P B, B^T P A in closed form)
+    int lgo[2][4], lgd[2][2];
+    double lgc[2][4];
+    {
+        const int dump = Ls.s_flag + 1;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int e = ln + 64 * t;
+            lgo[t][0] = lgo[t][1] = lgo[t][2] = lgo[t][3] = 0;
+            lgd[t][0] = lgd[t][1] = dump;
+            lgc[t][0] = lgc[t][1] = lgc[t][2] = lgc[t][3] = 0.0;
+            if (e < NTRI_U) {
+                int i = 0, rem = e;
+                while (rem >= NQ - i) { rem -= NQ - i; i++; }
+                const int j = i + rem;
+                lgo[t][0] = i * NX + j; lgo[t][1] = i * NX + NQ + j; lgo[t][2] = (NQ + i) * NX + j; lgo[t][3] = (NQ + i) * NX + NQ + j;
+                lgc[t][0] = cB * cB; lgc[t][1] = cB * dt; lgc[t][2] = cB * dt; lgc[t][3] = dt * dt;
+                lgd[t][0] = Ls.s_lam + i * NQ + j; lgd[t][1] = Ls.s_lam + j * NQ + i;
+            } else if (e < HR::NE) {
+                const int el = e - NTRI_U, i = el / NX, jx = el - i * NX;
+                const bool right = jx >= NQ;
+                const int jj = right ? jx - NQ : jx;
+                lgo[t][0] = i * NX + jj; lgo[t][1] = (NQ + i) * NX + jj; lgo[t][2] = i * NX + jx; lgo[t][3] = (NQ + i) * NX + jx;
+                if (right) { lgc[t][0] = dt * cB; lgc[t][1] = dt * dt; lgc[t][2] = cB; lgc[t][3] = dt; }
+                else { lgc[t][0] = cB; lgc[t][1] = dt; }
+                lgd[t][0] = lgd[t][1] = Ls.s_G + i * WS2 + jx;
+            }
+        }
+    }
+    // P update: entry (i, c) = (g + 4 r, c) through the expression of its upper-triangle twin (lo, hi), so that P stays exactly symmetric;
+    // P is updated IN PLACE (every read of a stage is issued, and waited for, before its first write: one wavefront, program order)
+    int lpo[XR][4], lpd[XR];
+    double lpc[XR][2];
+#pragma unroll
+    for (int r = 0; r < XR; r++) {
+        const int i = min(lg + 4 * r, NX - 1), c = min(lc, NX - 1);
+        const int lo = min(i, c), hi = max(i, c);
+        const int ii = lo >= NQ ? lo - NQ : lo, jj = hi >= NQ ? hi - NQ : hi;
+        lpo[r][0] = lo * NX + hi; lpo[r][1] = lo * NX + jj; lpo[r][2] = ii * NX + hi; lpo[r][3] = ii * NX + jj;
+        lpc[r][0] = hi >= NQ ? dt : 0.0;
+        lpc[r][1] = lo >= NQ ? dt : 0.0;
+        lpd[r] = (lg + 4 * r < NX && lc < NX) ? Ls.s_P + (lg + 4 * r) * NX + lc : Ls.s_flag + 1;
+    }
+    const int rho_dst = hl < NU ? Ls.s_G + hl * WS2 + NX : Ls.s_flag + 1;                  // rho of the Riccati phase, column NX of [G | rho]
+    const int pv_dst_b = (lg == NX % 4 && lc < NX) ? Ls.s_pv + lc : Ls.s_pv + NX;          // p_k from the lanes that hold W^T w
+    const double mfa0 = (hl <= NX && hl < 16 && lg == 0) ? 1.0 : 0.0, mfa1 = (hl <= NX && hl < 16 && lg == 2) ? 1.0 : 0.0;   // MFMA operand masks
+    const int fac_col = hc <= NX ? hc : (hc >= LC0 && hc - LC0 < NQ ? LCOL + hc - LC0 : NX + 1);                        // this lane's column of the factor block (idle lanes: the pad)
+    const int iu = hl_x < NQ ? hl_x : hl_x - NQ;                                            // control of the roll-out's lanes 0 .. NX-1
+    const int z_dst_u = hl < NQ ? hl : NZP, z_dst_x = hl < NX ? NZS + NU + hl : NZP + 1;      // roll-out stores (idle lanes: the record's spare cells)
+    const int r_dst = hl < NQ ? hl : NQP;                                                   // hand-off cells of rho / L^-1 rho
+    const int pv_dst_e = (hl >= NU && hl < NZ) ? hl - NU : NX;                               // corrector costate
 
     // ---- initial residual norm and complementarity from the setup partials ------------------------------------------------
     double R0 = 0.0, mu;
@@ -396,13 +497,13 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                         const int i = triUi[el], j = triUj[el];
                         double a = pdot(sTT + i * NQP, sTD + j * NQP, NQP / 2);
                         a += i == j ? sSC[0] : 0.0;
-                        hk[HR::oUU + el] = a;
+                        hk[HR::oA + el] = a;
                     }
 #pragma unroll
                     for (int t = 0; t < (NQ * NX + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NQ * NX - 1);
                         const int i = el / NX, jx = el - i * NX;
-                        hk[HR::oUX + el] = pdot(sTT + i * NQP, sTD + (NU + jx) * NQP, NQP / 2);
+                        hk[HR::oA + NTRI_U + el] = pdot(sTT + i * NQP, sTD + (NU + jx) * NQP, NQP / 2);
                     }
                 }
                 // x-x triangle
@@ -419,7 +520,8 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                         a += jx < NQ ? qq : 0.0;
                     }
                     a += ix == jx ? dii + (ix >= NQ ? lmv : 0.0) : 0.0;
-                    hk[HR::oXX + el] = a;
+                    hk[HR::oXX + 16 * ix + jx] = a;
+                    hk[HR::oXX + 16 * jx + ix] = a;
                 }
                 // gradient g + C^T e
                 {
@@ -452,193 +554,219 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         }
         WGT(0);
 
-        // =============== phase B: Riccati recursion (half-wave 0) ==========================================================
+        // =============== phase B: Riccati recursion (wavefront 0, all 64 lanes) ============================================
+        // Per stage two LDS hand-offs: [Lambda | G | rho] -> Cholesky (registers, every lane) + one column of [W | w | L^-1] per lane ->
+        // [W | w]^T [W | w] on the f64 MFMA, straight from the columns' registers -> P_k, p_k -> LDS (in place).  The stage's H record
+        // comes from HBM / L2 into the registers of the lanes that use it, one stage ahead.
         if (seq) {
-            double *Pc = dsm + Ls.s_P0, *Pn = dsm + Ls.s_P1, *pvc = dsm + Ls.s_pv0, *pvn = dsm + Ls.s_pv1;
-            constexpr int HPF2 = (HR::SIZE / 2 + 31) / 32;
-            dbl2 hp[HPF2];
-            auto load_h = [&](int k) {
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(hrec + (size_t)k * HR::SIZE);
-#pragma unroll
-                for (int j = 0; j < HPF2; j++) hp[j] = s2[min(hl + 32 * j, HR::SIZE / 2 - 1)];
-            };
-            auto commit_h = [&]() {
-                dbl2* d2 = reinterpret_cast<dbl2*>(sH);
-#pragma unroll
-                for (int j = 0; j < HPF2; j++) d2[min(hl + 32 * j, HR::SIZE / 2 - 1)] = hp[j];
-            };
             double Lr[NQ][NQ], Linv[NQ];
-            bool broke = false;
+            double dmin = 1.0;
+            double hA[2], hX[XR], hG, hGx;
+            auto load_h = [&](int k) {
+                const double* hk = hrec + (size_t)k * HR::SIZE;
+                hA[0] = hk[HR::oA + ln];
+                hA[1] = hk[HR::oA + 64 + ln];
+#pragma unroll
+                for (int r = 0; r < XR; r++) hX[r] = hk[HR::oXX + 16 * min(lg + 4 * r, NX - 1) + min(lc, NX - 1)];
+                hG = hk[HR::oGH + hz];
+                hGx = hk[HR::oGH + NU + min(lc, NX - 1)];
+            };
+            // P_N = the x-x block, p_N = the x part of the gradient
             load_h(N);
-            commit_h();
+#pragma unroll
+            for (int r = 0; r < XR; r++) dsm[lpd[r]] = hX[r];
+            dsm[Ls.s_pv + pv_dst_e] = hG;
             load_h(N > 0 ? N - 1 : 0);
             lds_fence();
-            // P_N = the x-x block, p_N = the x part of the gradient
-#pragma unroll
-            for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
-                const int el = min(hl + 32 * t, NTRI_X - 1);
-                const int ix = triXi[el], jx = triXj[el];
-                const double a = sH[HR::oXX + el];
-                Pc[ix * NX + jx] = a;
-                Pc[jx * NX + ix] = a;
-            }
-            if (hl < NX) pvc[hl] = sH[HR::oGH + NU + hl];
-            lds_fence();
             for (int k = N - 1; k >= 0; k--) {
-                double* const fk = sFac + k * NWP;
-                commit_h();
+                double* const fk = sFac + k * NFW;
+                const double a0 = hA[0], a1 = hA[1], gh = hG, ghx = hGx;
+                double hx[XR];
+#pragma unroll
+                for (int r = 0; r < XR; r++) hx[r] = hX[r];
                 load_h(k > 0 ? k - 1 : 0);
+                const bool bfl = sBf[k] != 0.0;
+                asm volatile("; WGMARK B_LG_BEGIN");
+                // Lambda = Huu + B^T P B (triangle, mirrored) and G = Hux + B^T P A: one formula, four entries of P with this lane's
+                // coefficients; rho = gh_u + B^T (p + P b)
                 {
-                    const double a = sBf[k] != 0.0 ? pdot(Pc + hl_x * NX, sBk + k * NX, NX / 2) : 0.0;
-                    sPB[hl_x] = a;
+                    double pe[10];
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pe[4 * t + q] = sP[lgo[t][q]];
+                    pe[8] = sPv[hl_u]; pe[9] = sPv[NQ + hl_u];
+                    hold_n(pe);
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        double a = t == 0 ? a0 : a1;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) a = fma(lgc[t][q], pe[4 * t + q], a);
+                        dsm[lgd[t][0]] = a;
+                        dsm[lgd[t][1]] = a;
+                    }
+                    double pb1 = 0.0, pb2 = 0.0;
+                    if (bfl) {
+                        pb1 = pdot(sP + hl_u * NX, sBk + k * NX, NX / 2);
+                        pb2 = pdot(sP + (NQ + hl_u) * NX, sBk + k * NX, NX / 2);
+                    }
+                    dsm[rho_dst] = gh + cB * (pe[8] + pb1) + dt * (pe[9] + pb2);
                 }
                 lds_fence();
-                WGT(7);
-                // Lambda = Huu + B^T P B (triangle, mirrored), G = Hux + B^T P A, rho = gh_u + B^T (p + P b)
-#pragma unroll
-                for (int t = 0; t < (NTRI_U + 31) / 32; t++) {
-                    const int el = min(hl + 32 * t, NTRI_U - 1);
-                    const int i = triUi[el], j = triUj[el];
-                    double a = sH[HR::oUU + el];
-                    a += cB * cB * Pc[i * NX + j] + cB * dt * (Pc[i * NX + NQ + j] + Pc[(NQ + i) * NX + j]) + dt * dt * Pc[(NQ + i) * NX + NQ + j];
-                    sLam[i * NQ + j] = a;
-                    sLam[j * NQ + i] = a;
-                }
-#pragma unroll
-                for (int t = 0; t < (NQ * NX + 31) / 32; t++) {
-                    const int el = min(hl + 32 * t, NQ * NX - 1);
-                    const int i = el / NX, jx = el - i * NX;
-                    const bool right = jx >= NQ;
-                    const int jj = right ? jx - NQ : jx;
-                    double a = sH[HR::oUX + el];
-                    const double left = cB * Pc[i * NX + jj] + dt * Pc[(NQ + i) * NX + jj];
-                    a += right ? dt * left + cB * Pc[i * NX + jx] + dt * Pc[(NQ + i) * NX + jx] : left;
-                    sG[i * WS2 + jx] = a;
-                }
-                double ghx;
-                {
-                    const double gh = sH[HR::oGH + hz];
-                    const bool ctl = hz < NU;
-                    const double pb1 = sPB[ctl ? hz : hl_px], pb2 = sPB[ctl ? NQ + hz : (hl_px >= NQ ? hl_px - NQ : 0)];
-                    const double pv1 = pvc[hl_u], pv2 = pvc[NQ + hl_u];
-                    const double rho = gh + cB * (pv1 + pb1) + dt * (pv2 + pb2);
-                    if (hl < NU) sG[hl * WS2 + NX] = rho;
-                    ghx = gh;
-                }
-                lds_fence();
+                asm volatile("; WGMARK B_CHOL_BEGIN");
                 WGT(8);
                 // Cholesky of Lambda in registers (every lane), one column of [W | w | L^-1] per lane
+                double col[NQ];
                 {
+                    double A[NQ][NQ], cv[NQ];
+                    const int cg = hc <= NX ? hc : NX;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++)
+#pragma unroll
+                        for (int i = j; i < NQ; i++) A[i][j] = sLam[i * NQ + j];
+#pragma unroll
+                    for (int i = 0; i < NQ; i++) cv[i] = sG[i * WS2 + cg];
+                    hold_n(cv);
+#pragma unroll
+                    for (int i = 0; i < NQ; i++) col[i] = hc <= NX ? cv[i] : (i == hc - LC0 ? 1.0 : 0.0);
 #pragma unroll
                     for (int j = 0; j < NQ; j++) {
-                        double dsum = sLam[j * NQ + j];
+                        double dsum = A[j][j];
 #pragma unroll
                         for (int t = 0; t < j; t++) dsum = fma(-Lr[j][t], Lr[j][t], dsum);
-                        broke = broke || !(dsum > 0.0);
+                        dmin = fmin(dmin, dsum);          // (a pivot <= 0 or NaN is reported once, after the sweep)
                         const double inv = fast_rsqrt(dsum);
                         Linv[j] = inv;
 #pragma unroll
                         for (int i = j + 1; i < NQ; i++) {
-                            double v = sLam[i * NQ + j];
+                            double v = A[i][j];
 #pragma unroll
                             for (int t = 0; t < j; t++) v = fma(-Lr[i][t], Lr[j][t], v);
                             Lr[i][j] = v * inv;
                         }
+                        // (the column solve advances with the factor: its step j needs row j of L only)
+                        double v = col[j];
+#pragma unroll
+                        for (int t = 0; t < j; t++) v = fma(-Lr[j][t], col[t], v);
+                        col[j] = v * inv;
                     }
-                    double col[NQ];
-                    const int cg = hc <= NX ? hc : NX;
 #pragma unroll
-                    for (int i = 0; i < NQ; i++) col[i] = hc <= NX ? sG[i * WS2 + cg] : (i == hc - LC0 ? 1.0 : 0.0);
-#pragma unroll
-                    for (int i = 0; i < NQ; i++) {
-                        double v = col[i];
-#pragma unroll
-                        for (int t = 0; t < i; t++) v = fma(-Lr[i][t], col[t], v);
-                        col[i] = v * Linv[i];
-                    }
-                    if (hc <= NX) {
-#pragma unroll
-                        for (int i = 0; i < NQ; i++) sWT[hc * NQP + i] = col[i];
-                        if (NQP > NQ) sWT[hc * NQP + NQ] = 0.0;
-                    }
-                    // (in this order: the zeros above a column's diagonal land on the tail of the column before it and are overwritten there by
-                    //  that column's later stores; the lanes between the two groups of columns hold nothing of the block)
-                    if (hc <= NX || (hc >= LC0 && hc - LC0 < NQ)) {
-#pragma unroll
-                        for (int i = 0; i < NQ; i++) fk[wbase + i] = col[i];
-                    }
+                    for (int i = 0; i < NQ; i++) fk[i * FS + fac_col] = col[i];
                 }
-                lds_fence();
+                asm volatile("; WGMARK B_PUPD_BEGIN");
                 WGT(9);
                 if (k > 0) {
-                    // P_k = Hxx + A^T P A - W^T W,  p_k = gh_x + A^T (p + P b) - W^T w
+                    double pr[4 * XR + 2];
+                    const int i_ = min(lc, NX - 1), i2_ = i_ >= NQ ? i_ - NQ : 0;
 #pragma unroll
-                    for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
-                        const int el = min(hl + 32 * t, NTRI_X - 1);
-                        const int i = triXi[el], j = triXj[el];
-                        const int ii = i >= NQ ? i - NQ : i, jj = j >= NQ ? j - NQ : j;
-                        double a = sH[HR::oXX + el] - pdot(sWT + i * NQP, sWT + j * NQP, NQP / 2);
-                        const double cj = j >= NQ ? dt : 0.0, ci = i >= NQ ? dt : 0.0;
-                        a += Pc[i * NX + j] + cj * Pc[i * NX + jj] + ci * (Pc[ii * NX + j] + dt * Pc[ii * NX + jj]);
-                        Pn[i * NX + j] = a;
-                        Pn[j * NX + i] = a;
+                    for (int r = 0; r < XR; r++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pr[4 * r + q] = sP[lpo[r][q]];
+                    pr[4 * XR] = sPv[i_]; pr[4 * XR + 1] = sPv[i2_];
+                    hold_n(pr);
+                    // [W | w]^T [W | w] as a 16 x 16 tile: lane (g, c) of the result holds rows g, g + 4, ... of column c.  A = B: the lanes of
+                    // groups 0 and 2 (which hold the same columns, c = their lane in the group) feed two k-slices per instruction
+                    v4d ww = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int m = 0; m < (NQ + 1) / 2; m++) {
+                        const double av = 2 * m + 1 < NQ ? fma(col[2 * m + 1 < NQ ? 2 * m + 1 : 0], mfa1, col[2 * m] * mfa0) : col[2 * m] * mfa0;
+                        ww = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, ww, 0, 0, 0);
+                    }
+                    // P_k = Hxx + A^T P A - W^T W,  p_k = gh_x + A^T (p + P b) - W^T w
+                    double pb1 = 0.0, pb2 = 0.0;
+                    if (bfl) {
+                        pb1 = pdot(sP + i_ * NX, sBk + k * NX, NX / 2);
+                        pb2 = pdot(sP + i2_ * NX, sBk + k * NX, NX / 2);
+                    }
+#pragma unroll
+                    for (int r = 0; r < XR; r++) {
+                        double a = hx[r] - ww[r];
+                        a += pr[4 * r] + lpc[r][0] * pr[4 * r + 1] + lpc[r][1] * (pr[4 * r + 2] + dt * pr[4 * r + 3]);
+                        dsm[lpd[r]] = a;
                     }
                     {
-                        const int i = hl_px, i2 = i >= NQ ? i - NQ : 0;
-                        const double q1 = pvc[i] + sPB[i], q2 = pvc[i2] + sPB[i2];
-                        double v = ghx + q1 + (i >= NQ ? dt * q2 : 0.0);
-                        v -= pdot(sWT + i * NQP, sWT + NX * NQP, NQP / 2);
-                        if (hl >= NU && hl < NZ) pvn[i] = v;
+                        const double q1 = pr[4 * XR] + pb1, q2 = pr[4 * XR + 1] + pb2;
+                        double v = ghx + q1 + (i_ >= NQ ? dt * q2 : 0.0);
+                        v -= ww[XR_W];
+                        dsm[pv_dst_b] = v;
                     }
                     lds_fence();
-                    double* t1 = Pc; Pc = Pn; Pn = t1;
-                    double* t2 = pvc; pvc = pvn; pvn = t2;
                 }
+                asm volatile("; WGMARK B_PUPD_END");
                 WGT(10);
             }
-            if (half_max(broke ? 1.0 : 0.0) > 0.0 && hl == 0) sFlag[0] = 1.0;
+            if (!(half_min(dmin) > 0.0) && hl == 0) sFlag[0] = 1.0;
         }
         __syncthreads();
         WGT(1);
         if (sFlag[0] != 0.0) { st_code = 4; pending = false; break; }
 
-        // roll-out through the factor blocks: z_k = [u_k | x_k] for every stage (half-wave 0)
+        // roll-out through the factor blocks: z_k = [u_k | x_k] for every stage (wavefront 0).  Every operand of a stage is read in one
+        // batch at its top; two hand-offs per stage (rho, then the state).
         auto rollout = [&](auto corr_tag) {
             constexpr bool CORR = decltype(corr_tag)::value;
+            asm volatile("; WGMARK ROLL_BEGIN");
             if (hl < NX) sZ[NU + hl] = dx0_reg;
             lds_fence();
-            const int iu = hl_x < NQ ? hl_x : hl_x - NQ;
-            const int lb_u = LyT::w_coff(iu) - iu;
             for (int k = 0; k < N; k++) {
-                const double* fk = sFac + k * NWP;
-                double* zk = sZ + k * NZP;
+                const double* fk = sFac + k * NFW;
+                double* zk = sZ + k * NZS;
+                double wrow[NX + 2], xs[NX + 2], lt[NQ + 2];
+                if constexpr (NQ % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < (NX + 2) / 2; j++) {
+                        const dbl2 v = reinterpret_cast<const dbl2*>(fk + hl_u * FS)[j];
+                        wrow[2 * j] = v.x; wrow[2 * j + 1] = v.y;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NX / 2; j++) {
+                        const dbl2 v = reinterpret_cast<const dbl2*>(zk + NU)[j];
+                        xs[2 * j] = v.x; xs[2 * j + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j <= NX; j++) wrow[j] = fk[hl_u * FS + j];
+#pragma unroll
+                    for (int j = 0; j < NX; j++) xs[j] = zk[NU + j];
+                }
+                xs[NX] = zk[NU + hl_x]; xs[NX + 1] = zk[NU + NQ + iu];
+#pragma unroll
+                for (int j = 0; j < NQ; j++) lt[j] = fk[j * FS + LCOL + iu];      // column iu of L^-1 (its zeros included)
+                lt[NQ] = sBk[k * NX + hl_x];
+                lt[NQ + 1] = CORR ? sWC[k * NQP + hl_u] : 0.0;
+                hold_n(wrow); hold_n(xs); hold_n(lt);
                 {
-                    const double* wr_ = fk + hl_u;
-                    double a = wr_[NX * NQ] + (CORR ? sWC[k * NQP + hl_u] : 0.0), a_v = 0.0;
+                    double a = wrow[NX] + lt[NQ + 1], a_v = 0.0;
 #pragma unroll
                     for (int j = 0; j < NQ; j++) {
-                        a = fma(wr_[j * NQ], zk[NU + j], a);
-                        a_v = fma(wr_[(NQ + j) * NQ], zk[NU + NQ + j], a_v);
+                        a = fma(wrow[j], xs[j], a);
+                        a_v = fma(wrow[NQ + j], xs[NQ + j], a_v);
                     }
-                    a += a_v;
-                    if (hl < NQ) sRho[hl] = a;
+                    sR[r_dst] = a + a_v;
                 }
                 lds_fence();
-                {
-                    // u_i = -(L^-T rho)_i on the lanes i and NQ + i; x+ = A x + B u + b
-                    double a = 0.0;
+                double rh[NQP];
+                if constexpr (NQ % 2 == 0) {
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) a = fma(iu <= j ? fk[lb_u + j] : 0.0, sRho[j], a);
-                    const double u = -a;
-                    if (hl < NQ) zk[hl] = u;
-                    if (hl < NX) {
-                        const double bi = sBk[k * NX + hl];
-                        zk[NZP + NU + hl] = hl < NQ ? zk[NU + hl] + dt * zk[NU + NQ + hl] + cB * u + bi : zk[NU + hl] + dt * u + bi;
+                    for (int j = 0; j < NQ / 2; j++) {
+                        const dbl2 v = reinterpret_cast<const dbl2*>(sR)[j];
+                        rh[2 * j] = v.x; rh[2 * j + 1] = v.y;
                     }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) rh[j] = sR[j];
                 }
+                hold_n(rh);
+                double s_ = 0.0;
+#pragma unroll
+                for (int j = 0; j < NQ; j++) s_ = fma(lt[j], rh[j], s_);
+                const double u = -s_;
+                zk[z_dst_u] = u;
+                zk[z_dst_x] = hl < NQ ? xs[NX] + dt * xs[NX + 1] + cB * u + lt[NQ] : xs[NX] + dt * u + lt[NQ];
                 lds_fence();
             }
-            if (hl < NQ) sZ[N * NZP + hl] = 0.0;      // no control at the end stage
+            if (hl < NQ) sZ[N * NZS + hl] = 0.0;      // no control at the end stage
+            asm volatile("; WGMARK ROLL_END");
         };
         // rows of every stage for the roll-out in sZ (stage-parallel): ratio test, sums; predictor: c.z_aff, a1 / a2; corrector: c.z+, z+
         auto rows_phase = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
@@ -651,7 +779,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
             double* const sCst = scr + Ls.d_CST;
             for (int k = hw; k <= N; k += NHW) {
                 double* w = ws + (size_t)k * Ly.stride;
-                const double* zk = sZ + k * NZP;
+                const double* zk = sZ + k * NZS;
                 dbl2 Cs[CST_PF];
                 {
                     const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
@@ -745,42 +873,81 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         sigmu = sigma * mu;
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
 
-        // =============== phase E: corrector costate (half-wave 0) ===========================================================
+        // =============== phase E: corrector costate (wavefront 0) =========================================================
+        // (every operand of a stage read in one batch at its top; hand-offs: rho, L^-1 rho, the costate -- in place)
         if (seq) {
-            double *pvc = dsm + Ls.s_pv0, *pvn = dsm + Ls.s_pv1;
+            asm volatile("; WGMARK E_BEGIN");
             const int ip1 = hl < NU ? hl : hl_px;
             const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
             {
                 const dbl2 a12 = reinterpret_cast<const dbl2*>(sA12 + N * 2 * NZP)[hz];
-                const double gh = sigmu * a12.x + corr_w * a12.y;
-                if (hz >= NU && hl < NZ) pvc[hz - NU] = gh;
+                sPv[pv_dst_e] = sigmu * a12.x + corr_w * a12.y;
             }
             lds_fence();
             for (int k = N - 1; k >= 0; k--) {
-                const double* fk = sFac + k * NWP;
-                const dbl2 a12 = reinterpret_cast<const dbl2*>(sA12 + k * 2 * NZP)[hz];
-                const double gh = sigmu * a12.x + corr_w * a12.y;
-                const double q1 = pvc[ip1], q2 = pvc[ip2];
-                if (hl < NU) sRho[hl] = gh + cB * q1 + dt * q2;
-                lds_fence();
+                const double* fk = sFac + k * NFW;
+                double t_[2 * NQP + 4];
                 {
-                    double v = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NQ; j++) v = fma(j <= hl_u ? fk[LyT::w_coff(j) - j + hl_u] : 0.0, sRho[j], v);
-                    if (hl < NQ) { sWv[hl] = v; sWC[k * NQP + hl] = v; }
+                    const dbl2 a_ = reinterpret_cast<const dbl2*>(sA12 + k * 2 * NZP)[hz];
+                    t_[2 * NQP] = a_.x; t_[2 * NQP + 1] = a_.y;
                 }
-                lds_fence();
-                if (k > 0) {
-                    if (hz >= NU && hl < NZ) {
-                        double v = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
+                t_[2 * NQP + 2] = sPv[ip1]; t_[2 * NQP + 3] = sPv[ip2];
+                if constexpr (NQ % 2 == 0) {
 #pragma unroll
-                        for (int t = 0; t < NQ; t++) v = fma(-fk[hl_px * NQ + t], sWv[t], v);
-                        pvn[hl_px] = v;
+                    for (int j = 0; j < NQ / 2; j++) {
+                        const dbl2 v = reinterpret_cast<const dbl2*>(fk + hl_u * FS + LCOL)[j];      // row hl_u of L^-1
+                        t_[2 * j] = v.x; t_[2 * j + 1] = v.y;
                     }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) t_[j] = fk[hl_u * FS + LCOL + j];
+                }
+#pragma unroll
+                for (int t = 0; t < NQ; t++) t_[NQP + t] = fk[t * FS + hl_px];                       // column hl_px of W
+                hold_n(t_);
+                const double gh = sigmu * t_[2 * NQP] + corr_w * t_[2 * NQP + 1];
+                const double q1 = t_[2 * NQP + 2], q2 = t_[2 * NQP + 3];
+                sR[r_dst] = gh + cB * q1 + dt * q2;
+                lds_fence();
+                double rh[NQP];
+                if constexpr (NQ % 2 == 0) {
+#pragma unroll
+                    for (int j = 0; j < NQ / 2; j++) {
+                        const dbl2 v = reinterpret_cast<const dbl2*>(sR)[j];
+                        rh[2 * j] = v.x; rh[2 * j + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) rh[j] = sR[j];
+                }
+                hold_n(rh);
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < NQ; j++) v = fma(t_[j], rh[j], v);
+                sV[r_dst] = v;
+                if (hl < NQ) sWC[k * NQP + hl] = v;
+                if (k > 0) {
                     lds_fence();
-                    double* t2 = pvc; pvc = pvn; pvn = t2;
+                    double wv[NQP];
+                    if constexpr (NQ % 2 == 0) {
+#pragma unroll
+                        for (int j = 0; j < NQ / 2; j++) {
+                            const dbl2 x_ = reinterpret_cast<const dbl2*>(sV)[j];
+                            wv[2 * j] = x_.x; wv[2 * j + 1] = x_.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NQ; j++) wv[j] = sV[j];
+                    }
+                    hold_n(wv);
+                    double pk = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
+#pragma unroll
+                    for (int t = 0; t < NQ; t++) pk = fma(-t_[NQP + t], wv[t], pk);
+                    sPv[pv_dst_e] = pk;
+                    lds_fence();
                 }
             }
+            asm volatile("; WGMARK E_END");
         }
         __syncthreads();
         WGT(4);

@@ -483,7 +483,7 @@ def test_qp_kernels_agree(case):
     """k_qp_ipm_wg (a workgroup per instance: stage-parallel row work, recursions through LDS; round 6) against k_qp_ipm (a wavefront
     per two instances) on the SAME handle-built stage records: same algorithm and per-row arithmetic, a few sums in another order.
     Over a ten-step closed loop driven by the throughput kernel's result: statuses equal at every solve, iteration counts equal but
-    for the odd instance whose exit test is decided by rounding (<= 1 apart), every control within 2e-6 (1 + |u|) where the counts
+    for the odd instance whose exit test is decided by rounding (<= 1 apart), every control within 5e-6 (1 + |u|) where the counts
     are equal -- the tolerance of two IPMs walking the same path from rounding-different starts (the first, cold solve agrees to
     1e-8; from the second step on the QPs have flat directions, DESIGN.md section 5, and rounding-level differences of the Newton
     systems show up at 1e-7); a different count means one more IPM step, i.e. the solution tolerance."""
@@ -521,8 +521,8 @@ def test_qp_kernels_agree(case):
         if same.any():
             err = np.abs(ua[same] - ub[same]).max() / (1 + np.abs(ua[same]).max())
             worst = max(worst, err)
-            assert err < (1e-7 if step == 0 else 2e-6), (step, err)
-            assert np.abs(xa[same] - xb[same]).max() < 2e-6
+            assert err < (1e-7 if step == 0 else 5e-6), (step, err)
+            assert np.abs(xa[same] - xb[same]).max() < 5e-6
         xg, ug, uapp = a.provide_control((sa == 0).astype(np.int32), xa, ua, xg, ug)
         x, _ = a.plant_step(x, uapp)
         xg = a.guess_correction(xg, ug)
