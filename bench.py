@@ -363,7 +363,9 @@ def main():
     if B < 1:
         raise SystemExit('strong scaling: fewer instances than ranks')
     N, nx, nu = HORIZON, prob.nx, prob.nu
-    S = max(1, min(args.streams, B // 256 or 1))
+    # (up to 512 instances the engine launches the latency form of the QP solve, a workgroup per instance: its launches have no tail
+    #  worth overlapping, and one launch over all instances lets the engine see the whole batch when it picks the form)
+    S = 1 if B <= 512 else max(1, min(args.streams, B // 256 or 1))
 
     # one solver handle (= one HIP stream + its own workspace) per sub-batch: independent instances, so the sub-batches
     # advance independently and the hardware overlaps the long tail of one with the bulk of another

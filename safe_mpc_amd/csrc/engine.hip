@@ -478,11 +478,15 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
 }
 
 // k_qp_ipm_wg (kernel_qp_wg.hpp), the latency form of the interior-point solve -- one workgroup per instance: -1 (default) chosen by
-// batch size, 0 never, 1 whenever its LDS fits (SMPC_QP_WG; A/B runs and the parity tests).  Below qp_wg_max_batch instances the
-// chip has wavefront slots to spare and a launch lasts as long as ONE instance's iterations; above it k_qp_ipm's two instances per
-// wavefront use the chip better (measured: DESIGN.md section 4c).
+// batch size, 0 never, 1 whenever its LDS fits (SMPC_QP_WG; smpc_set_qp_mode per handle).  Built with 8 half-wavefronts per
+// workgroup (four wavefronts, one per SIMD: one workgroup per CU -- up to qp_wg_full_batch instances run in one round) and with 4
+// (two wavefronts: two workgroups per CU, the stage-parallel phases take twice the rounds -- up to qp_wg_max_batch instances).  Above
+// that k_qp_ipm's two instances per wavefront use the chip better (measured: DESIGN.md section 4c).
+#ifndef QP_WG_FULL_BATCH
+#define QP_WG_FULL_BATCH 256
+#endif
 #ifndef QP_WG_MAX_BATCH
-#define QP_WG_MAX_BATCH 256
+#define QP_WG_MAX_BATCH 512
 #endif
 static int qp_wg_mode() {
     static const int v = [] { const char* e = getenv("SMPC_QP_WG"); return e ? atoi(e) : -1; }();
@@ -492,9 +496,23 @@ static int qp_wg_max_batch() {
     static const int v = [] { const char* e = getenv("SMPC_QP_WG_MAX_BATCH"); return e ? atoi(e) : QP_WG_MAX_BATCH; }();
     return v;
 }
+static int qp_wg_full_batch() {
+    static const int v = [] { const char* e = getenv("SMPC_QP_WG_FULL_BATCH"); return e ? atoi(e) : QP_WG_FULL_BATCH; }();
+    return v;
+}
 constexpr size_t QP_WG_LDS_LIMIT = 160 * 1024 - 512;     // one CU's LDS less the kernel's static tables
 
-template <int NQ>
+// half-wavefronts per workgroup for a launch of B instances (0: the latency form is not to be used)
+template <int NQ> int qp_wg_choice(const smpc_handle* h, int B) {
+    const int mode = h->qp_mode >= -1 ? h->qp_mode : qp_wg_mode();
+    if (mode == 0) return 0;
+    if (mode < 0 && B > qp_wg_max_batch()) return 0;
+    const auto fits = [&](int nhw) { return (size_t)WgLds<NQ>(h->N, h->desc.n_rows, nhw).total * sizeof(double) <= QP_WG_LDS_LIMIT; };
+    if (B <= qp_wg_full_batch() && fits(8)) return 8;
+    return fits(4) ? 4 : 0;
+}
+
+template <int NQ, int NHW>
 int launch_qp_wg(smpc_handle* h, int B, const double* x0, const double* xg, const double* ug, double* xo, double* uo, int32_t* st,
                  int32_t* it) {
     const size_t need = (size_t)B * (h->N + 1) * HRecLayout<NQ>::SIZE;
@@ -504,16 +522,16 @@ int launch_qp_wg(smpc_handle* h, int B, const double* x0, const double* xg, cons
         if ((rc = dev_alloc(h, &h->d_hrec, need))) return rc;
         h->hrec_doubles = need;
     }
-    const size_t lds = (size_t)WgLds<NQ>(h->N, h->desc.n_rows, QP_WG_NHW).total * sizeof(double);
+    const size_t lds = (size_t)WgLds<NQ>(h->N, h->desc.n_rows, NHW).total * sizeof(double);
 #define SMPC_WG_LAUNCH(MR_)                                                                                                        \
     do {                                                                                                                           \
         static size_t attr_set = 0;                                                                                                \
         if (lds > attr_set) {                                                                                                      \
-            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qp_ipm_wg<NQ, MR_, QP_WG_NHW>),                         \
+            HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qp_ipm_wg<NQ, MR_, NHW>),                               \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
             attr_set = lds;                                                                                                        \
         }                                                                                                                          \
-        hipLaunchKernelGGL((k_qp_ipm_wg<NQ, MR_, QP_WG_NHW>), dim3(B), dim3(32 * QP_WG_NHW), lds, h->stream, h->d_desc, B, h->N, x0, xg, \
+        hipLaunchKernelGGL((k_qp_ipm_wg<NQ, MR_, NHW>), dim3(B), dim3(32 * NHW), lds, h->stream, h->d_desc, B, h->N, x0, xg,         \
                            ug, h->d_ws, h->d_hrec, xo, uo, st, it, h->d_last_it, h->d_active, h->d_ord_hist);                      \
     } while (0)
     switch (h->desc.n_rows) {
@@ -523,13 +541,6 @@ int launch_qp_wg(smpc_handle* h, int B, const double* x0, const double* xg, cons
     }
 #undef SMPC_WG_LAUNCH
     return SMPC_OK;
-}
-
-template <int NQ> bool qp_wg_wanted(const smpc_handle* h, int B) {
-    const int mode = h->qp_mode >= -1 ? h->qp_mode : qp_wg_mode();
-    if (mode == 0) return false;
-    if ((size_t)WgLds<NQ>(h->N, h->desc.n_rows, QP_WG_NHW).total * sizeof(double) > QP_WG_LDS_LIMIT) return false;
-    return mode > 0 || B <= qp_wg_max_batch();
 }
 
 template <int NQ>
@@ -554,7 +565,8 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
         HIPCHK(h, hipEventRecord(h->ev_t[0], h->stream));
     }
     if ((rc = launch_stage_records<NQ>(h, B, x0, xg, ug, p, timed, path))) return rc;
-    const bool wg = qp_wg_wanted<NQ>(h, B);
+    const int wg_nhw = qp_wg_choice<NQ>(h, B);
+    const bool wg = wg_nhw > 0;
     const int32_t* order = nullptr;
     if (h->order_B == B && B > 1 && !wg) {
         hipLaunchKernelGGL(k_order_by_iters, dim3((B + ORD_PER_BLOCK - 1) / ORD_PER_BLOCK), dim3(64), 0, h->stream, B, h->d_last_it,
@@ -573,7 +585,7 @@ int launch_solve(smpc_handle* h, int B, const double* x0, const double* xg, cons
     }
     // non-temporal workspace accesses once this launch's workspace is well beyond the Infinity Cache (kernel_qp.hpp, k_qp_ipm)
     if (wg) {
-        if ((rc = launch_qp_wg<NQ>(h, B, x0, xg, ug, xo, uo, st, it))) return rc;
+        if ((rc = wg_nhw == 8 ? launch_qp_wg<NQ, 8>(h, B, x0, xg, ug, xo, uo, st, it) : launch_qp_wg<NQ, 4>(h, B, x0, xg, ug, xo, uo, st, it))) return rc;
     } else {
     const bool nt = qp_nt_mode() < 0 ? ws_doubles_per_instance(h->desc, h->N) * sizeof(double) * (size_t)B >= qp_nt_threshold : qp_nt_mode() > 0;
 #define SMPC_QP_LAUNCH(MR_, NT_)                                                                                                   \

@@ -95,9 +95,6 @@ __device__ unsigned long long g_wg_prof[16];
 #define WGT(i) do { } while (0)
 #endif
 
-#ifndef QP_WG_NHW
-#define QP_WG_NHW 8
-#endif
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 // "These N values are needed HERE": one empty asm that lists them all -- the compiler then issues every load behind them before this
