@@ -203,7 +203,8 @@ def cpu_baseline(prob, net, x0, xg, ug, p, budget_s=10.0, latency_solves=160):
                                    'mean': float(lat.mean()), 'solves': int(len(lat))},
             'sample': f'{done} instance-solves drawn cyclically from {len(x0)} C1 instances in the closed-loop state the GPU leg ended '
                       f'in (same x, shifted guess, p), OpenMP over instances, {dt:.1f} s; then {len(lat)} single-instance solves on one '
-                      f'thread; oracle/smpc_oracle.cpp -O3 (dual-number derivatives, dense stage algebra), a CPU restatement -- not acados'}
+                      f'thread; oracle/smpc_oracle.cpp -O3 (dual-number derivatives, dense stage algebra), a CPU restatement -- not acados; '
+                      f'PARITY UNPINNED: the oracle is held by first principles and its own frozen output, by no vector of the reference (DESIGN.md section 5)'}
 
 
 def cpu_baseline_latency(prob, net, states):
@@ -310,8 +311,8 @@ def main():
                          'section 8: 2 / 3 / 4 / 5 / 6 streams = 3.15 / 2.92 / 3.17 / 3.22 / 3.14 ms per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--noise', type=float, default=0.0,
-                    help='model noise in percent (BASELINE config 2): per-instance perturbed plants, 256 distinct draws of '
-                         'utils.py:138-166 laid out over the instances')
+                    help='model noise in percent (BASELINE config 2): one perturbed plant per instance, the draws of utils.py:138-166 '
+                         'seeded by the instance id')
     ap.add_argument('--control-noise', type=float, default=0.0, help='torque noise in percent of tau_max (env_model.py:196)')
     ap.add_argument('--no-loop-timing', action='store_true',
                     help='skip the extra pass (after the timed region) that records per-kernel HIP events of the loop')
@@ -382,9 +383,10 @@ def main():
     # model noise (BASELINE config 2, generate_urdf_noise.py:20-36): per-instance plants + one torque-noise draw per instance
     jt_all = tn_all = None
     if args.noise > 0:
-        from safe_mpc_amd.closed_loop import perturbed_joint_tables
-        small = perturbed_joint_tables(par, prob.nq, args.noise, np.arange(256))
-        jt_all = np.ascontiguousarray(small[(np.arange(B) + rank * B) % 256]).view(np.float64).reshape(B, prob.nq, -1)
+        # one plant per instance, seed = global instance id (the reference perturbs and reseeds per model,
+        # utils.py:126-171, generate_urdf_noise.py:32-36)
+        from safe_mpc_amd.closed_loop import perturbed_joint_tables_batched
+        jt_all = np.ascontiguousarray(perturbed_joint_tables_batched(par, prob.nq, args.noise, np.arange(B) + rank * B)).view(np.float64).reshape(B, prob.nq, -1)
     if args.control_noise > 0:
         tn_all = np.random.default_rng(1 + rank).normal(0.0, prob.tau_max * args.control_noise / 100, (B, nu))
 
@@ -705,7 +707,7 @@ def main():
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True,
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workload_tag + f': Z1-class 6-DoF, N=30, {args.batch} instances' + ('/GPU' if args.scaling == 'weak' else ' in total') +
-                                   (f', model noise {args.noise}% (256 plant draws) + torque noise {args.control_noise}%' if args.noise > 0 or args.control_noise > 0 else '') +
+                                   (f', model noise {args.noise}% (one plant per instance, seed = instance id) + torque noise {args.control_noise}%' if args.noise > 0 or args.control_noise > 0 else '') +
                                    ', controller ' + CONTROLLER +
                                    (' (soft terminal NN row, ' if CONTROLLER == 'st' else ' (NN row as configured, ') +
                                    'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',

@@ -88,6 +88,99 @@ def perturbed_joint_tables(params, nq, noise_pct, seeds):
     return out
 
 
+def _mv3(R, v):
+    """R [3, 3] (or [..., 3, 3]) times v [..., 3] with the sums written out: elementwise numpy only, so that a row of a batch gets the
+    same bits whatever the batch's size (a BLAS matmul may pick another kernel, and another summation order, per shape)."""
+    return R[..., :, 0] * v[..., None, 0] + R[..., :, 1] * v[..., None, 1] + R[..., :, 2] * v[..., None, 2]
+
+
+def _mm3(A, B):
+    """A [..., 3, 3] times B [..., 3, 3], sums written out (see _mv3)."""
+    return (A[..., :, 0, None] * B[..., None, 0, :] + A[..., :, 1, None] * B[..., None, 1, :]) + A[..., :, 2, None] * B[..., None, 2, :]
+
+
+def perturbed_joint_tables_batched(params, nq, noise_pct, seeds):
+    """The per-instance plant models of :func:`perturbed_joint_tables` for MANY seeds at once (BASELINE config 2: 65 536 instances,
+    seed = instance id): the same draws in the same order -- one ``default_rng(seed)`` per instance, ten draws per URDF
+    link in the reference's order (mass, ixx iyy izz ixy iyz ixz, x y z; utils.py:128, 138-166), bit for bit those of the per-seed
+    function -- and the lumping into joint tables as elementwise array arithmetic over the batch.  The per-seed function stays the
+    statement the tests hold this one against (draws equal to the bit, tables to 1e-13 of their scale: SerialChain lumps with
+    BLAS-backed matmuls, this one with written-out sums)."""
+    base = params.robot_descr
+    seeds = np.asarray(seeds, np.int64).reshape(-1)
+    B = len(seeds)
+    always_draw = bool(getattr(params, 'reference_quirks', True))
+    chain0 = SerialChain(base, nq)                      # structure: carriers of every link, joint frames, limits (not perturbed)
+    # nominal value of every field that is drawn for, in the reference's order
+    fields = []                                         # (link index, kind, a, b)
+    for li, l in enumerate(base.links):
+        if l.inertial is None:
+            continue
+        fields.append((li, 'm', 0, 0))
+        fields += [(li, 'I', a, b) for (a, b) in [(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (0, 2)]]
+        fields += [(li, 'c', k, 0) for k in range(3)]
+
+    def nominal(f):
+        l = base.links[f[0]].inertial
+        return l.mass if f[1] == 'm' else (l.inertia[f[2], f[3]] if f[1] == 'I' else l.origin.xyz[f[2]])
+    nom = np.array([nominal(f) for f in fields])
+    # (the magnitudes exactly as the per-seed function forms them: abs(v) * noise / 100 for mass and inertia, abs(v * noise / 100) for
+    #  the centre of mass)
+    mag = np.array([abs(v * noise_pct / 100) if f[1] == 'c' else abs(v) * noise_pct / 100 for f, v in zip(fields, nom)])
+    drawn = (mag > 0) | (always_draw and noise_pct > 0)
+    nd = int(drawn.sum())
+    U = np.zeros((B, len(fields)))
+    if nd:
+        R = np.empty((B, nd))
+        for r_, sd in enumerate(seeds):                 # one generator per instance, as the reference reseeds per model
+            R[r_] = np.random.default_rng(int(sd)).random(nd)
+        lo, hi = -mag[drawn], mag[drawn]
+        U[:, drawn] = lo + (hi - lo) * R                # Generator.uniform(low, high) = low + (high - low) * next_double
+    val = nom[None, :] + U                              # [B, fields]
+    # lump: every link's inertial into the actuated link that carries it
+    m = np.zeros((B, nq))
+    mc = np.zeros((B, nq, 3))
+    parts = [[] for _ in range(nq)]
+    col = 0
+    for li, l in enumerate(base.links):
+        if l.inertial is None:
+            continue
+        mass, ent, xyz = val[:, col], val[:, col + 1:col + 7], val[:, col + 7:col + 10]
+        col += 10
+        if l.name not in chain0._carrier:
+            continue
+        idx, Rc, pc = chain0._carrier[l.name]
+        if idx < 0:
+            continue
+        I = np.empty((B, 3, 3))
+        for e_, (a, b) in enumerate([(0, 0), (1, 1), (2, 2), (0, 1), (1, 2), (0, 2)]):
+            I[:, a, b] = ent[:, e_]
+            I[:, b, a] = ent[:, e_]
+        c = pc + _mv3(Rc, xyz)
+        Ro = Rc @ l.inertial.origin.R                   # (constants of the model)
+        Ic = _mm3(_mm3(np.broadcast_to(Ro, (B, 3, 3)), I), np.broadcast_to(Ro.T, (B, 3, 3)))
+        m[:, idx] += mass
+        mc[:, idx] += mass[:, None] * c
+        parts[idx].append((mass, c, Ic))
+    out = np.zeros((B, nq), JOINT_DTYPE)
+    eye = np.eye(3)
+    for i, j in enumerate(chain0.joints):
+        if np.any(m[:, i] <= 0):
+            raise ValueError(f'link moved by {j.name} has no mass')
+        com = mc[:, i] / m[:, i, None]
+        I = np.zeros((B, 3, 3))
+        for (mi, ci, Ici) in parts[i]:
+            d = ci - com
+            dd = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]
+            I += Ici + mi[:, None, None] * (dd[:, None, None] * eye - d[:, :, None] * d[:, None, :])
+        o = out[:, i]
+        o['R0'], o['p0'], o['axis'] = j.R0.reshape(-1), j.p0, j.axis
+        o['mass'], o['com'] = m[:, i], com
+        o['inertia'] = np.stack([I[:, 0, 0], I[:, 0, 1], I[:, 0, 2], I[:, 1, 1], I[:, 1, 2], I[:, 2, 2]], axis=1)
+        o['q_min'], o['q_max'], o['v_max'], o['tau_max'] = j.q_min, j.q_max, j.v_max, j.tau_max
+    return out
+
+
 # ---- warm-start generation ----------------------------------------------------------------------------------------------------
 def merit_terms(ctrl, x0, x, u):
     """Pieces of the l1 merit function of the OCP at the iterate (x, u), per instance, from one batched linearisation

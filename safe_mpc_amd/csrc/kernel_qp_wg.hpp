@@ -82,7 +82,7 @@ template <int NQ> struct WgLds {
         s_G = s; s += NQ * WS2;
         s_R = s; s += NQP + 2;               // rho of a stage (hand-off inside the roll-outs / the corrector's recursion) + dump
         s_V = s; s += NQP + 2;               // L^-1 rho of the corrector's recursion + dump
-        s_red = s; s += 4 * NHW;
+        s_red = s; s += 4 * 8;               // (eight groups whatever the workgroup size: block_reduce)
         s_flag = s; s += 2;
         total = s;
     }
@@ -247,16 +247,31 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         }
         return s0 + s1;
     };
-    // max / sum / sum over the whole workgroup; every thread gets the result (fixed order: half-waves 0, 1, ...)
-    auto block_reduce = [&](double& vmax, double& s1, double& s2) {
-        vmax = half_max(vmax); s1 = half_sum(s1); s2 = half_sum(s2);
-        if (hl == 0) { sRed[4 * hw] = vmax; sRed[4 * hw + 1] = s1; sRed[4 * hw + 2] = s2; }
+    // max / sum / sum over the whole workgroup; every thread gets the result.  The sums are taken in an order that does not depend on
+    // the workgroup's size: stage k belongs to group k mod 8 (a lane adds its stages of a group in increasing order, then the 32
+    // lanes, then the groups 0 .. 7), so a workgroup of 4 half-waves, which owns two groups per half-wave, gets the bits of one of 8.
+    constexpr int NVG = 8, GPH = NVG / NHW;        // groups, groups per half-wave
+    static_assert(NVG % NHW == 0 && NHW <= NVG, "half-waves per workgroup: 8, 4, 2 or 1");
+    auto block_reduce = [&](double& vmax, double (&s1)[GPH], double (&s2)[GPH]) {
+        vmax = half_max(vmax);
+#pragma unroll
+        for (int g = 0; g < GPH; g++) {
+            const double a_ = half_sum(s1[g]), c_ = half_sum(s2[g]);
+            if (hl == 0) { sRed[4 * (hw + g * NHW) + 1] = a_; sRed[4 * (hw + g * NHW) + 2] = c_; }
+        }
+        if (hl == 0) sRed[4 * hw] = vmax;
         __syncthreads();
         double m = sRed[0], a = sRed[1], c = sRed[2];
 #pragma unroll
-        for (int j = 1; j < NHW; j++) { m = fmax(m, sRed[4 * j]); a += sRed[4 * j + 1]; c += sRed[4 * j + 2]; }
-        vmax = m; s1 = a; s2 = c;
+        for (int j = 1; j < NVG; j++) { if (j < NHW) m = fmax(m, sRed[4 * j]); a += sRed[4 * j + 1]; c += sRed[4 * j + 2]; }
+        vmax = m; s1[0] = a; s2[0] = c;
         __syncthreads();
+    };
+    // this stage's group among the GPH of the half-wave
+    auto add_to_group = [&](double (&acc)[GPH], int k, double v) {
+        const int g_ = (k / NHW) % GPH;
+#pragma unroll
+        for (int g = 0; g < GPH; g++) acc[g] += (g_ == g) ? v : 0.0;
     };
 
     // where piece j of a stage's [Tt | Gt | gn | b | scalars] goes in the row-major scratch of the row phases (as in k_qp_ipm's
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         if (mu <= tol && rho_lin * R0 <= tol_r) { st_code = 0; break; }
 
         // =============== phase A: rows + P-independent blocks of every stage ==============================================
-        double mu_new = 0.0;
+        double mu_new[GPH] = {};
         {
             double* const scr = dsm + hw * Ls.SCR_A;       // (over the factor blocks and a1 / a2 of the previous iteration: dead)
             double* const sIMG = scr;
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                     double Dr;
                     sE[hr] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
                     sD[hr] = Dr;
-                    mu_new += row_live ? qp_row_comp(rs, soft, wsoft) : 0.0;
+                    add_to_group(mu_new, k, row_live ? qp_row_comp(rs, soft, wsoft) : 0.0);
                 }
                 zc += alpha * (znc - zc);
                 w[Ly.oZ + hz] = zc;
@@ -541,9 +556,9 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
             }
         }
         if (pending) {
-            double dummy_m = 0.0, dummy_s = 0.0;
+            double dummy_m = 0.0, dummy_s[GPH] = {};
             block_reduce(dummy_m, mu_new, dummy_s);      // (ends with a barrier: phase A's stores are visible to wavefront 0)
-            mu = mu_new * inv_m;
+            mu = mu_new[0] * inv_m;
             pending = false;
             if (!(mu == mu)) { st_code = 4; break; }
         } else {
@@ -768,7 +783,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         // rows of every stage for the roll-out in sZ (stage-parallel): ratio test, sums; predictor: c.z_aff, a1 / a2; corrector: c.z+, z+
         auto rows_phase = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
-            double rr = 0.0, S1 = 0.0, S2 = 0.0;
+            double rr = 0.0, S1[GPH] = {}, S2[GPH] = {};
             double* const scr = dsm + Ls.o_scrd + hw * Ls.SCR_D;
             double* const sD = scr + Ls.d_D;
             double* const sE = scr + Ls.d_E;
@@ -819,8 +834,8 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                         w[Ly.oCZN + hr] = cz;
                         w[Ly.oZN + hz] = zk[hz];
                     }
-                    S1 += row_live ? s1_ : 0.0;
-                    S2 += row_live ? s2_ : 0.0;
+                    add_to_group(S1, k, row_live ? s1_ : 0.0);
+                    add_to_group(S2, k, row_live ? s2_ : 0.0);
                 }
                 if (!CORR) {
                     lds_fence();
@@ -853,7 +868,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 lds_fence();
             }
             block_reduce(rr, S1, S2);
-            *rr_out = rr; *S1_out = S1; *S2_out = S2;
+            *rr_out = rr; *S1_out = S1[0]; *S2_out = S2[0];
         };
 
         // =============== phases C, D: predictor ============================================================================
@@ -995,7 +1010,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         }
     }
     {
-        double d1 = 0.0, d2 = 0.0;
+        double d1[GPH] = {}, d2[GPH] = {};
         block_reduce(bad, d1, d2);
     }
     WGT(12);

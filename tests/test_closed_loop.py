@@ -56,6 +56,19 @@ def test_model_noise_tables_and_file_names():
     assert np.array_equal(jt[0]['axis'], base['axis']) and np.array_equal(jt[0]['p0'], base['p0'])
     zero = cl.perturbed_joint_tables(par, 6, 0.0, [5])
     assert np.allclose(zero[0]['mass'], base['mass']) and np.allclose(zero[0]['inertia'], base['inertia'])
+    # the batched generator (BASELINE config 2's 65 536 plants) against the per-seed statement: the draws to the bit (mass and centre
+    # of mass are sums and quotients of drawn values only), the lumped inertias to rounding (BLAS matmuls there, written-out sums here)
+    for quirks in (True, False):
+        par.reference_quirks = quirks
+        seeds = np.arange(64) * 1021 + 3
+        a, b = cl.perturbed_joint_tables(par, 6, 10.0, seeds), cl.perturbed_joint_tables_batched(par, 6, 10.0, seeds)
+        for fld in a.dtype.names:
+            if fld == 'inertia':
+                assert np.abs(a[fld] - b[fld]).max() <= 1e-15 * np.abs(a[fld]).max()
+            else:
+                assert np.array_equal(a[fld], b[fld]), fld
+    par.reference_quirks = True
+    assert np.array_equal(cl.perturbed_joint_tables_batched(par, 6, 10.0, [7])[0]['mass'], cl.perturbed_joint_tables_batched(par, 6, 10.0, np.arange(16))[7]['mass'])
     f = cl.guess_file(par, 'z1', 'st', 30, True)
     assert f.endswith('z1_st_30hor_10sm_use_netTrue__q_collision_margins_0.0_0.0_guess.pkl')
     g = cl.result_file(par, 'z1', 'st', 30, True, 5.0, 1.0, 0.0, 0.0)

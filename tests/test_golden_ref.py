@@ -75,7 +75,7 @@ def check_against_ref(g, solve, oracle, par):
 @pytest.mark.parametrize('path', REF_FILES or [None])
 def test_oracle_against_reference_vectors(path):
     if path is None:
-        pytest.skip('no tests/golden/ref_*.npz: the reference cannot run in this pipeline (DESIGN.md section 5); see INTEGRATION.md section 5')
+        pytest.skip(f'{len(REF_FILES)} reference-produced vector files (tests/golden/ref_*.npz) found: parity unpinned -- the reference cannot run in this pipeline (DESIGN.md section 5); see INTEGRATION.md section 5')
     from oracle.oracle import Oracle
     g = dict(np.load(path, allow_pickle=False))
     par, prob, net = problem_of(g)
@@ -87,7 +87,7 @@ def test_oracle_against_reference_vectors(path):
 @pytest.mark.parametrize('path', REF_FILES or [None])
 def test_engine_against_reference_vectors(path):
     if path is None:
-        pytest.skip('no tests/golden/ref_*.npz (see test_oracle_against_reference_vectors)')
+        pytest.skip(f'{len(REF_FILES)} reference-produced vector files (tests/golden/ref_*.npz) found: parity unpinned (see test_oracle_against_reference_vectors)')
     from oracle.oracle import Oracle
     from safe_mpc_amd.solver import BatchedOcpSolver
     g = dict(np.load(path, allow_pickle=False))

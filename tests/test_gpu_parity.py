@@ -159,9 +159,21 @@ def test_full_size_properties():
     assert np.allclose(x[ok, 1:, :6], x[ok, :-1, :6] + dt * x[ok, :-1, 6:] + 0.5 * dt * dt * u[ok], atol=1e-9)
     assert np.allclose(x[ok, 1:, 6:], x[ok, :-1, 6:] + dt * u[ok], atol=1e-9)
     assert np.all(x[ok, 1:] >= prob.lbx - 1e-6) and np.all(x[ok, 1:] <= prob.ubx + 1e-6)
-    # determinism and batch-independence: a sub-batch gives bit-identical results
+    # determinism and batch-independence.  The engine picks the FORM of the QP solve by batch size (smpc_set_qp_mode: k_qp_ipm for
+    # 4096 instances, k_qp_ipm_wg for 100), and the two agree to rounding, not to the bit: with the form fixed a sub-batch gives
+    # bit-identical results in either form; with the engine's own choice it stays inside the kernels' mutual tolerance
+    # (test_qp_kernels_agree)
     x2, u2, st2, it2 = s.solve(x0[:100], xg[:100], ug[:100], p[:100])
-    assert np.array_equal(x2, x[:100]) and np.array_equal(u2, u[:100]) and np.array_equal(it2, it[:100])
+    assert np.array_equal(st2, st[:100]) and np.abs(it2.astype(int) - it[:100].astype(int)).max() <= 1
+    same = it2 == it[:100]
+    assert np.abs(u2[same] - u[:100][same]).max() < 1e-7 * (1 + np.abs(u).max())
+    s.set_qp_mode('throughput')
+    x3, u3, st3, it3 = s.solve(x0[:100], xg[:100], ug[:100], p[:100])
+    assert np.array_equal(x3, x[:100]) and np.array_equal(u3, u[:100]) and np.array_equal(it3, it[:100])
+    s.set_qp_mode('latency')
+    x4, u4, st4, it4 = s.solve(x0[:300], xg[:300], ug[:300], p[:300])          # (300: the 4-half-wave workgroups; 100: the 8-half-wave ones)
+    assert np.array_equal(x2, x4[:100]) and np.array_equal(u2, u4[:100]) and np.array_equal(it2, it4[:100])
+    s.set_qp_mode('auto')
     # spot parity against the oracle on a slice
     from oracle.oracle import Oracle
     o = Oracle(prob, (net.weights, net.biases))
