@@ -300,7 +300,10 @@ def main():
     # more expensive with time, and the 3 + 20 window of rounds 1-4 flattered `value` by ~18 %
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=B_PER_GPU, help='instances per GPU')
+    ap.add_argument('--config', choices=['c1', 'c2', 'c3', 'c4'], default='c1',
+                    help="BASELINE.json's configs: c1 Z1 N=30 x 4096 (the headline); c2 the same with one perturbed plant per instance x 65536; "
+                         'c3 the horizon x alpha grid, 32768 over 8 GPUs grouped by horizon; c4 7-DoF N=40, row on every node, 131072 over 8 GPUs')
+    ap.add_argument('--batch', type=int, default=None, help='instances per GPU (weak) / in total (strong); default: the config\'s own size')
     ap.add_argument('--graphs', type=int, default=0,
                     help='1: replay each sub-batch step as a captured hipGraph (one host launch per sub-batch and step instead of '
                          '~25; measured on one GPU: no gain, DESIGN.md section 7 -- kept for A/B runs on a node whose ranks share '
@@ -310,6 +313,7 @@ def main():
                          'independently and the long tail of one QP launch overlaps the bulk of another (round 4, DESIGN.md '
                          'section 8: 2 / 3 / 4 / 5 / 6 streams = 3.15 / 2.92 / 3.17 / 3.22 / 3.14 ms per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-latency', action='store_true', help='skip the one-instance latency measurement added to the C1 line')
     ap.add_argument('--noise', type=float, default=0.0,
                     help='model noise in percent (BASELINE config 2): one perturbed plant per instance, the draws of utils.py:138-166 '
                          'seeded by the instance id')
@@ -352,43 +356,57 @@ def main():
     if init_only:
         use_dist = False
 
-    from safe_mpc_amd.sharding import gather_to_root, shard_range
+    from safe_mpc_amd.sharding import gather_to_root, shard_by_horizon, shard_range
     from safe_mpc_amd.solver import BatchedOcpSolver
-    par, prob, net = build_problem()
-    if args.scaling == 'strong':
-        lo_r, hi_r = shard_range(args.batch, world, rank)
-        B = hi_r - lo_r
-        B_total = args.batch
+    from safe_mpc_amd.controller import get_controller
+    cfg = args.config
+    controller = 'constraint_everywhere' if cfg == 'c4' else CONTROLLER
+    # ---- the instances of this rank: a list of groups, each one problem (one horizon) with the global ids of its instances ----------
+    #   c1 / c2  Z1, N = 30; weak: --batch per GPU; strong: --batch in total, split by shard_range
+    #   c3       the horizon x alpha grid of run_mpc_horizons.sh:19-34 / run_mpc_alphas.sh:19-34 (N in 20..40 x alpha in 20..50), grouped
+    #            by horizon (a handle has one N) and every group sliced over the ranks (shard_by_horizon); weak: every rank owns one
+    #            eighth of an 8 x --batch grid (BASELINE: 32 768 over 8 GPUs), strong: --batch in total over the ranks that are there
+    #   c4       7-DoF Franka-class, N = 40, row on every node; weak: --batch per GPU (BASELINE: 131 072 over 8 = 16 384), strong: split
+    per_gpu_default = {'c1': B_PER_GPU, 'c2': 65536, 'c3': 4096, 'c4': 16384}[cfg]
+    if args.batch is None:
+        args.batch = per_gpu_default if args.scaling == 'weak' else per_gpu_default * (8 if cfg in ('c3', 'c4') else 1)
+    if cfg == 'c2':
+        args.noise = args.noise if args.noise > 0 else 10.0                 # BASELINE config 2: model-noise Monte Carlo
+        args.control_noise = args.control_noise if args.control_noise > 0 else 1.0
+    if cfg == 'c4':
+        from safe_mpc_amd.parser import Parameters
+        from safe_mpc_amd.problem import OcpProblem
+        from safe_mpc_amd.safe_set import SafeSetNet
+        par = Parameters({}, 'fr7', filename=os.path.join(ROOT, 'config_fr7.yaml'))
+        par.N = 40
+        prob = OcpProblem(par, controller, 'ext', N=40)
+        net = SafeSetNet.from_params(par, prob.x_min, prob.x_max)
+        prob.set_normalisation(net.mean, net.std)
     else:
-        B, B_total = args.batch, args.batch * world
+        par, prob, net = build_problem()
+    nx, nu, nq = prob.nx, prob.nu, prob.nq
+
+    def partition(r):
+        """{horizon: global instance ids} owned by rank r, and the job's total"""
+        if cfg == 'c3':
+            n_full = args.batch * 8 if args.scaling == 'weak' else args.batch
+            horizons = np.repeat([20, 25, 30, 35, 40], n_full // 5 + 1)[:n_full]
+            return shard_by_horizon(horizons, 8 if args.scaling == 'weak' else world, r % 8 if args.scaling == 'weak' else r), \
+                (args.batch * world if args.scaling == 'weak' else n_full)
+        if args.scaling == 'strong':
+            lo_r, hi_r = shard_range(args.batch, world, r)
+            return {prob.N: np.arange(lo_r, hi_r)}, args.batch
+        return {prob.N: np.arange(args.batch) + r * args.batch}, args.batch * world
+    owned, B_total = partition(rank)
+    B = int(sum(len(v) for v in owned.values()))
     if B < 1:
         raise SystemExit('strong scaling: fewer instances than ranks')
-    N, nx, nu = HORIZON, prob.nx, prob.nu
+    N = prob.N
     # (up to 512 instances the engine launches the latency form of the QP solve, a workgroup per instance: its launches have no tail
     #  worth overlapping, and one launch over all instances lets the engine see the whole batch when it picks the form)
     S = 1 if B <= 512 else max(1, min(args.streams, B // 256 or 1))
 
-    # one solver handle (= one HIP stream + its own workspace) per sub-batch: independent instances, so the sub-batches
-    # advance independently and the hardware overlaps the long tail of one with the bulk of another
-    solvers = [BatchedOcpSolver(prob, net, device=local) for _ in range(S)]
-    # (strong scaling: every rank draws from its own stretch of the Halton sequence, like weak -- instances are independent)
-    x0_h = initial_states(solvers[0], prob, B, rank)
-    xg_h = np.repeat(x0_h[:, None, :], N + 1, axis=1)
-    ug_h = np.zeros((B, N, nu))
-    p_h = np.zeros((B, N + 1, 5))
-    p_h[:, :, :3], p_h[:, :, 3], p_h[:, :, 4] = prob.ee_ref, par.alpha, 1.0
-
     t = lambda a, dt=torch.float64: torch.tensor(a, dtype=dt, device=dev)
-
-    # model noise (BASELINE config 2, generate_urdf_noise.py:20-36): per-instance plants + one torque-noise draw per instance
-    jt_all = tn_all = None
-    if args.noise > 0:
-        # one plant per instance, seed = global instance id (the reference perturbs and reseeds per model,
-        # utils.py:126-171, generate_urdf_noise.py:32-36)
-        from safe_mpc_amd.closed_loop import perturbed_joint_tables_batched
-        jt_all = np.ascontiguousarray(perturbed_joint_tables_batched(par, prob.nq, args.noise, np.arange(B) + rank * B)).view(np.float64).reshape(B, prob.nq, -1)
-    if args.control_noise > 0:
-        tn_all = np.random.default_rng(1 + rank).normal(0.0, prob.tau_max * args.control_noise / 100, (B, nu))
 
     # Results for rank 0: every sub-batch writes the applied control and the status of each step into its slice of a rollout
     # log -- straight from the engine's kernels (u_out / status pointers of smpc_policy_step), no copy -- and ONE gather of the
@@ -401,35 +419,65 @@ def main():
     u_log = gather_in[:K_log * B * nu * 8].view(torch.float64).view(K_log, B, nu)
     st_log = gather_in[K_log * B * nu * 8:].view(torch.int32).view(K_log, B)
 
-    from safe_mpc_amd.controller import get_controller
-
     class Sub:
         pass
-    subs = []
-    for i, sv in enumerate(solvers):
-        lo, hi = shard_range(B, S, i)
-        sb = Sub()
-        sb.solver, sb.n, sb.off = sv, hi - lo, lo
-        sb.stream = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
-        with torch.cuda.stream(sb.stream):
-            # the reference's controller object for these instances, all of its state in HBM (safe_mpc_amd/controller.py)
-            sb.ctrl = get_controller(CONTROLLER, par, sb.n, cost='ext', N=N, solver=sv, net=net, device=local, device_state=True)
-            sb.ctrl.setGuess(t(xg_h[lo:hi]), t(ug_h[lo:hi]))
-            sb.ctrl.p.copy_(t(p_h[lo:hi]))
-            sb.x_sim, sb.x_next = t(x0_h[lo:hi]), t(x0_h[lo:hi])
-            sb.u_eff = torch.empty((sb.n, nu), dtype=torch.float64, device=dev)
-            sb.acc = torch.zeros((3,), dtype=torch.int64, device=dev)      # [sum of IPM iterations, failed solves, solves]
-            sb.jt = t(jt_all[lo:hi]) if jt_all is not None else None
-            sb.tn = t(tn_all[lo:hi]) if tn_all is not None else None
-            sb.status_home = sb.ctrl.last_status
-            sb.u_stage = torch.empty((sb.n, nu), dtype=torch.float64, device=dev)       # (--graphs 1: the step's control before it
-            sb.slot_dev = torch.zeros((1,), dtype=torch.int64, device=dev)             #  is copied to log row slot_dev)
-        sb.tsum, sb.tcnt = np.zeros(5), 0
-        subs.append(sb)
-    if args.scaling == 'strong':
-        sizes_all = [shard_range(args.batch, world, r)[1] - shard_range(args.batch, world, r)[0] for r in range(world)]
-    else:
-        sizes_all = [B] * world
+    subs, off = [], 0
+    probe_sv = BatchedOcpSolver(prob, net, device=local)                 # (collision filter of the initial states; the roofline probe)
+    starts512 = initial_states(probe_sv, prob, 512, rank) if cfg == 'c3' else None
+    for Ng, gids in owned.items():
+        if cfg == 'c3':
+            par_g, prob_g, net_g = build_problem(N=int(Ng))
+            # one sub-batch (= handle = stream) per horizon group: five of them share the GPU
+            pieces = [(0, len(gids))]
+        else:
+            par_g, prob_g, net_g = par, prob, net
+            pieces = [shard_range(len(gids), S, i) for i in range(S)]
+        # model noise (BASELINE config 2, generate_urdf_noise.py:20-36): one plant per instance, seed = GLOBAL instance id (SURVEY 8(d)
+        # C2; the reference perturbs and reseeds per model, utils.py:126-171), + one torque-noise draw per instance (env_model.py:196)
+        jt_g = tn_g = None
+        if args.noise > 0:
+            from safe_mpc_amd.closed_loop import perturbed_joint_tables_batched
+            jt_g = np.ascontiguousarray(perturbed_joint_tables_batched(par_g, nq, args.noise, gids)).view(np.float64).reshape(len(gids), nq, -1)
+        if args.control_noise > 0:
+            tn_g = np.random.default_rng(1 + rank).normal(0.0, prob_g.tau_max * args.control_noise / 100, (len(gids), nu))
+        if cfg == 'c3':
+            x0_g = starts512[gids % 512]
+        else:
+            x0_g = initial_states(probe_sv, prob_g, len(gids), rank)
+            if cfg == 'c4':
+                x0_g[:, nq:] = 0.1 * np.random.default_rng(rank).uniform(-1, 1, (len(gids), nq)) * prob_g.ubx[nq:]
+        p_g = np.zeros((len(gids), Ng + 1, 5))
+        p_g[:, :, :3], p_g[:, :, 3], p_g[:, :, 4] = prob_g.ee_ref, par_g.alpha, 1.0
+        if cfg == 'c3':
+            p_g[:, :, 3] = np.array([20.0, 30.0, 40.0, 50.0])[gids % 4][:, None]          # alpha rides per instance (run_mpc_alphas.sh:19)
+        for lo, hi in pieces:
+            sv = BatchedOcpSolver(prob_g, net_g, device=local)
+            sb = Sub()
+            sb.solver, sb.n, sb.off, sb.N = sv, hi - lo, off + lo, int(Ng)
+            sb.par, sb.prob, sb.net = par_g, prob_g, net_g
+            sb.x0_h, sb.p_h = x0_g[lo:hi], p_g[lo:hi]
+            sb.stream = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
+            with torch.cuda.stream(sb.stream):
+                # the reference's controller object for these instances, all of its state in HBM (safe_mpc_amd/controller.py)
+                sb.ctrl = get_controller(controller, par_g, sb.n, cost='ext', N=int(Ng), solver=sv, net=net_g, device=local, device_state=True)
+                sb.ctrl.setGuess(t(np.repeat(sb.x0_h[:, None, :], Ng + 1, axis=1)), t(np.zeros((sb.n, Ng, nu))))
+                sb.ctrl.p.copy_(t(sb.p_h))
+                sb.x_sim, sb.x_next = t(sb.x0_h), t(sb.x0_h)
+                sb.u_eff = torch.empty((sb.n, nu), dtype=torch.float64, device=dev)
+                sb.acc = torch.zeros((3,), dtype=torch.int64, device=dev)      # [sum of IPM iterations, failed solves, solves]
+                sb.jt = t(jt_g[lo:hi]) if jt_g is not None else None
+                sb.tn = t(tn_g[lo:hi]) if tn_g is not None else None
+                sb.status_home = sb.ctrl.last_status
+                sb.u_stage = torch.empty((sb.n, nu), dtype=torch.float64, device=dev)       # (--graphs 1: the step's control before it
+                sb.slot_dev = torch.zeros((1,), dtype=torch.int64, device=dev)             #  is copied to log row slot_dev)
+            sb.tsum, sb.tcnt = np.zeros(5), 0
+            subs.append(sb)
+        off += len(gids)
+    solvers = [sb.solver for sb in subs]
+    S = len(subs)
+    sizes_all = [int(sum(len(v) for v in partition(r)[0].values())) for r in range(world)]
+    if cfg == 'c3' and args.scaling == 'weak':
+        B_total = int(sum(sizes_all))        # (the horizon groups do not divide evenly: the first ranks take the remainders)
     # receive buffers of the per-step gather are allocated once, outside the timed loop
     gather_bufs = None
     if use_dist:
@@ -588,12 +636,17 @@ def main():
     # roofline probe of the dominant kernel (k_qp_ipm): ONE launch over the whole batch, alone on the GPU, HIP events on
     # the engine's stream around each phase (the per-launch duration rocprofv3 --kernel-trace reports for the same launch)
     roof = None
+    # (a grid of horizons, C3, is probed on its N = 30 group: a handle has one horizon)
+    probe_N = 30 if any(sb.N == 30 for sb in subs) else subs[0].N
+    psubs = [sb for sb in subs if sb.N == probe_N]
+    prob, net, N = psubs[0].prob, psubs[0].net, probe_N
+    Bp = int(sum(sb.n for sb in psubs))
     if rank == 0:
-        sv = BatchedOcpSolver(prob, net, device=local)
+        sv = probe_sv if probe_sv.N == probe_N else BatchedOcpSolver(prob, net, device=local)
         st_ = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
         with torch.cuda.stream(st_):
-            xs = torch.cat([sb.x_sim for sb in subs]); xgf = torch.cat([sb.ctrl.x_guess for sb in subs])
-            ugf = torch.cat([sb.ctrl.u_guess for sb in subs]); pf = torch.cat([sb.ctrl.p for sb in subs])
+            xs = torch.cat([sb.x_sim for sb in psubs]); xgf = torch.cat([sb.ctrl.x_guess for sb in psubs])
+            ugf = torch.cat([sb.ctrl.u_guess for sb in psubs]); pf = torch.cat([sb.ctrl.p for sb in psubs])
         torch.cuda.synchronize()
         sv.enable_timing(True)
         acc = np.zeros(8)
@@ -612,27 +665,31 @@ def main():
                     tm['qp_wave_busy_mean'], tm['qp_wave_span']]
         acc /= probes
         it_probe /= probes
-        alg = algorithmic_bytes(prob.nq, N) * B
+        alg = algorithmic_bytes(prob.nq, N) * Bp
         ach = alg / acc[5] / 1e9
+        # the form of the QP solve the engine picks for a launch of this size (engine.hip: qp_wg_choice; smpc_set_qp_mode)
+        qp_kernel = 'k_qp_ipm_wg' if Bp <= 512 else 'k_qp_ipm'
         # FLOP fractions: algorithmic flops of the launch / its HIP-event duration / peak
         nh = prob.nq + prob.desc.n_rows + 1
-        qp_fl = qp_flops_per_iteration(prob.nq, N, nh) * it_probe * B
-        mlp_rows = B if prob.desc.nn_mode == 1 else (B * N if prob.desc.nn_mode == 2 else 0)
+        qp_fl = qp_flops_per_iteration(prob.nq, N, nh) * it_probe * Bp
+        mlp_rows = Bp if prob.desc.nn_mode == 1 else (Bp * N if prob.desc.nn_mode == 2 else 0)
         mlp_fl = mlp_flops_per_row(prob.nq) * mlp_rows
         # HBM bytes come from separate rocprofv3 --pmc passes over scripts/qp_bench.py (counters cannot be read from inside this
         # process).  The committed file holds bytes per INSTANCE-ITERATION of k_qp_ipm (the kernel's traffic is proportional to
         # the iterations it runs); traffic of THIS probe launch = that x the probe's own iteration count x instances, so that
         # traffic / kernel time is the rate of the launch that was timed here.  null when there is no file for this round's kernel.
         traffic, traffic_rate, traffic_src, bpi = None, None, None, None
-        for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json'):
+        tag_ = ('_wg' if qp_kernel == 'k_qp_ipm_wg' else '') + ('_c4' if cfg == 'c4' else '')
+        for name in (f'r06_pmc_traffic{tag_}.json', f'r05_pmc_traffic{tag_}.json'):
             tf = os.path.join(ROOT, 'profiles', name)
-            if bpi is None and os.path.exists(tf) and CONTROLLER == 'st':
+            if bpi is None and os.path.exists(tf) and controller in ('st', 'constraint_everywhere'):
                 tj = json.load(open(tf))
                 bpi = tj.get('bytes_per_instance_iteration')
                 if bpi:
-                    traffic = bpi * it_probe * B
+                    bpi = bpi * (N + 1) / (41.0 if cfg == 'c4' else 31.0)       # (the kernel moves a fixed number of bytes per stage)
+                    traffic = bpi * it_probe * Bp
                     traffic_rate, traffic_src = traffic / acc[5] / 1e9, 'profiles/' + name
-        roof = {'bound': 'hbm', 'kernel': 'k_qp_ipm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        roof = {'bound': 'hbm', 'kernel': qp_kernel, 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'traffic_bytes_per_instance_iteration': bpi, 'traffic_GBps': traffic_rate,
                 'flop_frac_qp_fp64': qp_fl / acc[5] / 1e12 / FP64_VALU_PEAK_TF,
@@ -650,11 +707,16 @@ def main():
                               'solve_total': acc[3] * 1e3,
                               'note': 'ONE launch over the whole batch, alone on the GPU (the roofline probe) -- not the timed loop'},
                 'kernel_ms_in_loop': in_loop,
-                'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={B}, alone on the GPU, closed-loop state after the timed steps'}
+                'algorithmic_bytes_per_launch': alg, 'launch': f'one launch, B={Bp}, N={N}, alone on the GPU, closed-loop state after the timed steps'}
+        if len(psubs) < len(subs):
+            # several horizons share the GPU (C3): every group's launch inside the loop, algorithmic bytes / HIP-event duration
+            tl = [(sb, sb.tsum / sb.tcnt) for sb in subs if sb.tcnt > 0]
+            if tl:
+                roof['in_loop_all_groups'] = roofline_of_launches([algorithmic_bytes(sb.prob.nq, sb.N) * sb.n for sb, _ in tl], [1e3 * t_[3] for _, t_ in tl])
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        nb = min(B, 1024)
+        nb = min(Bp, 1024)
         h = lambda a: a[:nb].cpu().numpy()
         cpu = cpu_baseline(prob, net, h(xs), h(xgf), h(ugf), h(pf))
 
@@ -670,10 +732,9 @@ def main():
     elif world == 1 and not args.no_survey_window and not args.graphs:
         for sb in subs:
             with torch.cuda.stream(sb.stream):
-                lo, hi = sb.off, sb.off + sb.n
-                sb.ctrl.setGuess(t(xg_h[lo:hi]), t(ug_h[lo:hi]))
-                sb.ctrl.p.copy_(t(p_h[lo:hi]))
-                sb.x_sim.copy_(t(x0_h[lo:hi]))
+                sb.ctrl.setGuess(t(np.repeat(sb.x0_h[:, None, :], sb.N + 1, axis=1)), t(np.zeros((sb.n, sb.N, nu))))
+                sb.ctrl.p.copy_(t(sb.p_h))
+                sb.x_sim.copy_(t(sb.x0_h))
                 if hasattr(sb.ctrl, 'fails'):
                     sb.ctrl.fails.zero_()
         barrier()
@@ -695,23 +756,47 @@ def main():
 
     if rank == 0:
         total = B_total * args.steps
-        # BASELINE.json's configs by BOTH of their defining properties: C1 = 4096 instances without model noise, C2 = 65 536 with it
-        if args.noise > 0:
-            workload_tag = 'C2' if args.batch == 65536 else f'C2-like (model noise, {args.batch} instead of 65536 instances)'
+        per = '/GPU' if args.scaling == 'weak' else ' in total'
+        nn_txt = ' (soft terminal NN row, ' if controller == 'st' else ' (NN row as configured, '
+        if cfg in ('c1', 'c2'):
+            std = args.batch == (65536 if cfg == 'c2' else B_PER_GPU)
+            tag = cfg.upper() if std else f'{cfg.upper()}-like ({args.batch} instead of {65536 if cfg == "c2" else B_PER_GPU} instances)'
+            workload = (tag + f': Z1-class 6-DoF, N=30, {args.batch} instances{per}' +
+                        (f', model noise {args.noise}% (one plant per instance, seed = instance id) + torque noise {args.control_noise}%' if args.noise > 0 or args.control_noise > 0 else '') +
+                        ', controller ' + controller + nn_txt + 'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0')
+            metric = f'RTI-MPC instance-steps/s (batch={args.batch}{" per GPU" if args.scaling == "weak" else " in total"}, Z1 N=30)'
+        elif cfg == 'c3':
+            workload = (f'C3: horizon x alpha grid of run_mpc_horizons.sh / run_mpc_alphas.sh (N in 20..40 x alpha in 20..50), {B_total} instances in total, '
+                        f'grouped by horizon and sliced over {8 if args.scaling == "weak" else world} shares (this rank: {B} instances, ' +
+                        ', '.join(f'N={sb.N}: {sb.n}' for sb in subs) + '), Z1-class 6-DoF, controller ' + controller + nn_txt +
+                        'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0')
+            metric = f'RTI-MPC instance-steps/s (horizon x alpha grid, {B} instances per GPU, Z1 N=20..40)'
         else:
-            workload_tag = 'C1' if args.batch == B_PER_GPU else f'C1-like ({args.batch} instead of {B_PER_GPU} instances)'
+            workload = (f'C4: 7-DoF Franka-class (config_fr7.yaml), N=40, {args.batch} instances{per}, controller {controller} (NN row on every node, '
+                        'MLP 14-256-256-256-1 fp32), EXT cost exact Hessian, sphere obstacle + floor rows, Halton x0')
+            metric = f'RTI-MPC instance-steps/s (batch={args.batch}{" per GPU" if args.scaling == "weak" else " in total"}, 7-DoF N=40)'
+        extra = {}
+        if cfg == 'c1' and world == 1 and not args.no_latency:
+            # the reference's own statistic for this path: the solver time per step of ONE instance (scripts/mpc.py:300-303; budget dt = 5 ms)
+            try:
+                extra['latency_b1_ms'] = small_batch_latency(N=HORIZON, batches=(1,), n_steps=100, device=local)[0]
+            except Exception as e:      # (never lose the line to the side measurement)
+                extra['latency_b1_ms'] = {'error': f'{type(e).__name__}: {e}'}
+            pf_ = os.path.join(ROOT, 'profiles', 'r06_strong_scaling_proxy.json')
+            if os.path.exists(pf_):
+                rows_ = json.load(open(pf_))['rows']
+                extra['strong_proxy'] = {'source': 'profiles/r06_strong_scaling_proxy.json (scripts/latency_scaling.py: bench.py --batch <per-GPU share> on one GPU; '
+                                                   'instances are independent, one gather per rollout)',
+                                         'ms_per_step_by_share': {str(r_['batch']): r_['ms_per_step'] for r_ in rows_},
+                                         'predicted_speedup_by_gpus': {str(r_['gpus_at_4096_total']): r_['predicted_strong_speedup'] for r_ in rows_}}
         line = {
-            'metric': 'RTI-MPC instance-steps/s (batch=4096 per GPU, Z1 N=30)' if args.scaling == 'weak' else
-                      'RTI-MPC instance-steps/s (batch=4096 in total, Z1 N=30)',
+            'metric': metric,
             'value': total / elapsed, 'unit': 'instance-steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / max(args.steps, 1), 'higher_is_better': True,
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': workload_tag + f': Z1-class 6-DoF, N=30, {args.batch} instances' + ('/GPU' if args.scaling == 'weak' else ' in total') +
-                                   (f', model noise {args.noise}% (one plant per instance, seed = instance id) + torque noise {args.control_noise}%' if args.noise > 0 or args.control_noise > 0 else '') +
-                                   ', controller ' + CONTROLLER +
-                                   (' (soft terminal NN row, ' if CONTROLLER == 'st' else ' (NN row as configured, ') +
-                                   'MLP 12-256-256-256-1 fp32), EXT cost exact Hessian, 6 capsule pairs, Halton x0',
-                       'batch_per_gpu': B, 'batch_total': B_total, 'horizon': N, 'controller': CONTROLLER, 'streams_per_gpu': S,
+            'config': {'workload': workload, 'name': cfg,
+                       'batch_per_gpu': B, 'batch_total': B_total, 'horizon': sorted({sb.N for sb in subs}) if cfg == 'c3' else N,
+                       'controller': controller, 'streams_per_gpu': S,
                        'hip_graphs': bool(subs[0].graph is not None),
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
                        'failed_instance_steps': fails},
@@ -720,6 +805,7 @@ def main():
             'host_issue_ms_per_step': 1e3 * host_issue / max(args.steps, 1), 'usable_cores': usable_cores(),
             'roofline': roof, 'cpu_baseline': cpu, 'survey_window': survey,
         }
+        line.update(extra)
         if log_check is not None:
             line['log_check'] = log_check
         sys.stdout.flush()

@@ -9,7 +9,7 @@ export SMPC_HIP_LIB=$D/safe_mpc_amd/csrc/libsmpc_hip_exp.so
 mkdir -p $D/gpurun_out/c4pad
 for pad in 0 8192 13824 22016; do
  for fm in 8192 100000000; do
-  SMPC_QP_PAD_LDS=$pad SMPC_MLP_FUSED_MAX=$fm python $D/scripts/c4_bench.py 10 2 > $D/gpurun_out/c4pad/c4_${pad}_${fm}.json 2>>$D/gpurun_out/c4pad/err.txt
+  SMPC_QP_PAD_LDS=$pad SMPC_MLP_FUSED_MAX=$fm python $D/bench.py --config c4 --steps 10 --warmup 2 --no-cpu-baseline --no-survey-window > $D/gpurun_out/c4pad/c4_${pad}_${fm}.json 2>>$D/gpurun_out/c4pad/err.txt
   python -c "
 import json
 d=json.load(open('$D/gpurun_out/c4pad/c4_${pad}_${fm}.json')); print('pad', $pad, 'fused_max', $fm, 'ms/step %.2f' % d['ms_per_step'], {k: round(v,2) for k,v in d['kernel_ms_in_loop'].items()})"

@@ -29,7 +29,7 @@ def proxy(batches, extra_env=None):
     rows = []
     for b in batches:
         env = dict(os.environ, **(extra_env or {}))
-        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', str(b), '--no-cpu-baseline', '--no-loop-timing']
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--batch', str(b), '--no-cpu-baseline', '--no-loop-timing', '--no-latency']
         t0 = time.time()
         out = subprocess.run(cmd, env=env, capture_output=True, text=True)
         if out.returncode != 0:

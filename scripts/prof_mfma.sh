@@ -2,7 +2,7 @@
 # MFMA utilisation of the network pass's kernels: one rocprofv3 --pmc pass (SQ_INSTS_VALU_MFMA_MOPS_F32; only --kernel-trace beside
 # it, the program directly after `--`) over scripts/qp_bench.py on BASELINE config 4's problem (row on every node: 5461 x 40 network
 # rows per launch), kernels alone on the GPU; TFLOP/s = MOPS_F32 x 512 flop / kernel duration (the counter's definition), against the
-# dense fp32 MFMA peak of 157.3 TFLOP/s.  "In the loop": the same MOPS over the kernel's average duration inside scripts/c4_bench.py's
+# dense fp32 MFMA peak of 157.3 TFLOP/s.  "In the loop": the same MOPS over the kernel's average duration inside bench.py --config c4's
 # three-stream loop (rocprofv3 --kernel-trace of the loop: profiles/rNN_c4_kernel_summary_by_grid.txt).
 #   usage: prof_mfma.sh <outdir-name> [trace summary of the loop]
 set -e

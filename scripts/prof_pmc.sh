@@ -4,7 +4,7 @@
 #   usage: prof_pmc.sh <outdir-name> [case: c1 (default) | c1nt | c4]
 #   c1    C1's whole-batch launch (4096 instances, Z1, N = 30), workspace-size policy -> nt variant from round 5 on (733 MB > 384 MB)
 #   c1nt  the same with SMPC_QP_NT=1 forced / c1plain with SMPC_QP_NT=0 forced (A/B of the two access variants)
-#   c4    BASELINE config 4's problem (7-DoF, N = 40, row on every node) at one sub-batch launch of scripts/c4_bench.py (5461 instances)
+#   c4    BASELINE config 4's problem (7-DoF, N = 40, row on every node) at one sub-batch launch of bench.py --config c4 (5461 instances)
 set -e
 export TMPDIR=/tmp
 R=/root/repo
@@ -15,7 +15,7 @@ case $CASE in
   c1) ;;
   c1nt) export SMPC_QP_NT=1; LABEL="$LABEL, non-temporal variant forced" ;;
   c1plain) export SMPC_QP_NT=0; LABEL="$LABEL, plain-access variant forced"; KN="k_qp_ipm<6,6,false>" ;;
-  c4) export SMPC_QPB_PROBLEM=fr7; B=5461; LABEL="C4 problem (7-DoF, N=40, NN row on every node) after 5 closed-loop steps, one sub-batch launch of c4_bench.py"; KN="k_qp_ipm<7,4,true>" ;;
+  c4) export SMPC_QPB_PROBLEM=fr7; B=5461; LABEL="C4 problem (7-DoF, N=40, NN row on every node) after 5 closed-loop steps, one sub-batch launch of bench.py --config c4"; KN="k_qp_ipm<7,4,true>" ;;
 esac
 mkdir -p $O
 cd /tmp

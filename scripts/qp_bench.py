@@ -6,7 +6,7 @@ import numpy as np, torch
 import bench
 from safe_mpc_amd.solver import BatchedOcpSolver
 
-# SMPC_QPB_PROBLEM=fr7: BASELINE config 4's problem (7-DoF, N = 40, row on every node) at one sub-batch launch of scripts/c4_bench.py
+# SMPC_QPB_PROBLEM=fr7: BASELINE config 4's problem (7-DoF, N = 40, row on every node) at one sub-batch launch of bench.py --config c4
 FR7 = os.environ.get('SMPC_QPB_PROBLEM') == 'fr7'
 if FR7:
     from safe_mpc_amd.parser import Parameters
@@ -25,7 +25,7 @@ s = BatchedOcpSolver(prob, net)
 B = int(os.environ.get('SMPC_B', '5461' if FR7 else '4096'))
 x0 = bench.initial_states(s, prob, B, 0)
 if FR7:
-    x0[:, prob.nq:] = 0.1 * np.random.default_rng(0).uniform(-1, 1, (B, prob.nq)) * prob.ubx[prob.nq:]      # (as scripts/c4_bench.py)
+    x0[:, prob.nq:] = 0.1 * np.random.default_rng(0).uniform(-1, 1, (B, prob.nq)) * prob.ubx[prob.nq:]      # (as bench.py --config c4)
 N = prob.N
 xg = np.repeat(x0[:, None, :], N + 1, axis=1); ug = np.zeros((B, N, prob.nq)); p = np.zeros((B, N + 1, 5))
 p[:, :, :3], p[:, :, 3], p[:, :, 4] = prob.ee_ref, par.alpha, 1.0

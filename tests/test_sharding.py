@@ -206,3 +206,67 @@ def test_two_rank_gloo_strong_scaling_grouped_by_horizon_matches_single_process(
         want = _solve_group(N, idx, alphas, x0_all)
         assert np.array_equal(got[order][idx, 1:], want), N
     assert (got[:, -1] == 0).all()
+
+
+# ---- C4's partition end to end: the 7-DoF problem split by shard_range (bench.py --config c4 --scaling strong) -----
+def _solve_fr7(idx, x0_all):
+    """two closed-loop steps of the instances `idx` of the 7-DoF / row-on-every-node problem with the CPU test double"""
+    from conftest import make_problem_fr7
+    from fake_solver import OracleSolver
+    par, prob, net = make_problem_fr7(N=6)
+    s = OracleSolver(prob, net)
+    x = x0_all[idx]
+    xg, ug, p = constant_guess(prob, x, alpha=par.alpha)
+    out = np.zeros((len(idx), prob.nu + 1))
+    for _ in range(2):
+        xg = s.guess_correction(xg, ug)
+        xt, ut, st, it = s.solve(x, xg, ug, p)
+        xg, ug, u = s.provide_control((st == 0).astype(np.int32), xt, ut, xg, ug)
+        x = s.plant_step(x, u)[0]
+        out[:, :prob.nu], out[:, prob.nu] = u, st
+    return out
+
+
+def _worker_c4(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from conftest import make_problem_fr7
+    from safe_mpc_amd.sharding import gather_to_root
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    par, prob, net = make_problem_fr7(N=6)
+    total = 7                                                        # (uneven on purpose: 4 + 3)
+    x0_all = sample_instances(prob, total, seed=9)
+    lo, hi = shard_range(total, world, rank)
+    idx = np.arange(lo, hi)
+    local = torch.tensor(np.hstack([idx[:, None].astype(float), _solve_fr7(idx, x0_all)]))
+    got = gather_to_root(local)                                      # ONE gather: [global index | u | status]
+    if rank == 0:
+        q.put(got.numpy())
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_c4_split_matches_single_process():
+    import torch.multiprocessing as mp
+    from conftest import make_problem_fr7
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_c4, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert np.array_equal(got[:, 0], np.arange(7))                  # contiguous slices arrive in rank order
+    par, prob, net = make_problem_fr7(N=6)
+    x0_all = sample_instances(prob, 7, seed=9)
+    want = _solve_fr7(np.arange(7), x0_all)
+    assert np.array_equal(got[:, 1:], want)                         # instances are independent: bit-identical on the same code path
+    assert got.shape[1] == 1 + 7 + 1
