@@ -414,31 +414,37 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
             double* const sE = scr + Ls.a_E;
             double* const sTD = scr + Ls.a_TD;
             double* const sGD = scr + Ls.a_GD;
+            // (the records of this half-wave's NEXT stage are requested as soon as the registers of this one are free: a stage-round
+            //  otherwise starts with a full HBM / L2 latency, 500-800 clocks of the ~5000 a round takes)
+            dbl2 img[IMG_PF], pr0, pr1, pr2, pslb;
+            double pcza, pczn, pz, pzn;
+            auto load_a = [&](int k) {
+                const double* w = ws + (size_t)k * Ly.stride;
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
+#pragma unroll
+                for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
+                pr0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr]; pr1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr];
+                pr2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
+                pcza = w[Ly.oCZA + hr]; pczn = w[Ly.oCZN + hr];
+                pslb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
+                pz = w[Ly.oZ + hz]; pzn = w[Ly.oZN + hz];
+            };
+            load_a(min(hw, N));
             for (int k = hw; k <= N; k += NHW) {
                 const bool last = (k == N);
                 double* w = ws + (size_t)k * Ly.stride;
                 double* hk = hrec + (size_t)k * HR::SIZE;
-                dbl2 img[IMG_PF];
-                {
-                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
-#pragma unroll
-                    for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
-                }
-                QpRow rs;
-                {
-                    const dbl2 r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr], r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr],
-                               r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
-                    rs.lo = r0.x; rs.hi = r0.y; rs.tl = r1.x; rs.tu = r1.y; rs.ll = r2.x; rs.lu = r2.y;
-                }
-                const double czar = w[Ly.oCZA + hr], cznr = w[Ly.oCZN + hr];
-                const dbl2 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                double zc = w[Ly.oZ + hz];
-                const double znc = w[Ly.oZN + hz];
                 {
                     dbl2* d2 = reinterpret_cast<dbl2*>(sIMG);
 #pragma unroll
                     for (int j = 0; j < IMG_PF; j++) d2[min(hl + 32 * j, img_n2 - 1)] = img[j];
                 }
+                QpRow rs;
+                rs.lo = pr0.x; rs.hi = pr0.y; rs.tl = pr1.x; rs.tu = pr1.y; rs.ll = pr2.x; rs.lu = pr2.y;
+                const double czar = pcza, cznr = pczn, znc = pzn;
+                const dbl2 slb = pslb;
+                double zc = pz;
+                load_a(min(k + NHW, N));
                 const double wsoft = slb.x;
                 {
                     const bool soft = soft_lane && wsoft >= 0.0;
@@ -789,24 +795,29 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
             double* const sE = scr + Ls.d_E;
             double* const sBS = scr + Ls.d_BS;
             double* const sCst = scr + Ls.d_CST;
+            dbl2 Cs[CST_PF], qr0, qr1, qr2;
+            double qcza = 0.0;
+            auto load_r = [&](int k) {
+                const double* w = ws + (size_t)k * Ly.stride;
+                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
+#pragma unroll
+                for (int j = 0; j < CST_PF; j++) Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
+                qr0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr]; qr1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr];
+                qr2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
+                if (CORR) qcza = w[Ly.oCZA + hr];
+            };
+            load_r(min(hw, N));
             for (int k = hw; k <= N; k += NHW) {
                 double* w = ws + (size_t)k * Ly.stride;
                 const double* zk = sZ + k * NZS;
-                dbl2 Cs[CST_PF];
-                {
-                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
-#pragma unroll
-                    for (int j = 0; j < CST_PF; j++) Cs[j] = s2[min(hl + 32 * j, c_n2 - 1)];
-                }
-                const dbl2 r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr], r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr],
-                           r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
-                double cza = 0.0;
-                if (CORR) cza = w[Ly.oCZA + hr];
 #pragma unroll
                 for (int j = 0; j < CST_PF; j++) {
                     scr[cdst[j] & 0xffff] = Cs[j].x;
                     scr[cdst[j] >> 16] = Cs[j].y;
                 }
+                const dbl2 r0 = qr0, r1 = qr1, r2 = qr2;
+                const double cza = qcza;
+                load_r(min(k + NHW, N));       // (the next stage of this half-wave, a whole stage-round ahead)
                 lds_fence();
                 {
                     const double* cr = sCst + hl_c * NZP;

@@ -112,6 +112,23 @@ __global__ __launch_bounds__(64) void k_probe(double* out, unsigned long long* c
     t1 = __builtin_readcyclecounter();
     if (l == 0) clk[8] = t1 - t0;
     a += acc;
+    // accuracy of v_rsq_f64 and of one / two Newton steps on it (max relative error against 1 / sqrt over 64 x 256 arguments)
+    {
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0;
+        for (int i = 0; i < 256; i++) {
+            const double xx = (1.0 + l * 0.0371 + i * 0.00113) * (i % 3 == 0 ? 1e-6 : (i % 3 == 1 ? 1.0 : 3.7e5));
+            const double ref = 1.0 / sqrt(xx);
+            double y = __builtin_amdgcn_rsq(xx);
+            e0 = fmax(e0, fabs(y - ref) / ref);
+            const double hx = 0.5 * xx;
+            y = fma(fma(-hx * y, y, 0.5), y, y);
+            e1 = fmax(e1, fabs(y - ref) / ref);
+            y = fma(fma(-hx * y, y, 0.5), y, y);
+            e2 = fmax(e2, fabs(y - ref) / ref);
+        }
+        for (int o = 32; o > 0; o >>= 1) { e0 = fmax(e0, __shfl_xor(e0, o)); e1 = fmax(e1, __shfl_xor(e1, o)); e2 = fmax(e2, __shfl_xor(e2, o)); }
+        if (l == 0) { out[64] = e0; out[65] = e1; out[66] = e2; }
+    }
     // 9: empty timer pair
     t0 = __builtin_readcyclecounter();
     t1 = __builtin_readcyclecounter();
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(64) void k_probe(double* out, unsigned long long* c
 }
 int main() {
     double* out; unsigned long long* clk;
-    hipMalloc(&out, 64 * 8); hipMalloc(&clk, 16 * 8);
+    hipMalloc(&out, 72 * 8); hipMalloc(&clk, 16 * 8);
     for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, out, clk, 1.25);
     hipDeviceSynchronize();
     unsigned long long h[16];
@@ -132,5 +149,8 @@ int main() {
     const int per[] = {REP, 4 * REP, REP, REP, REP, REP, REP, REP, REP, 1};
     printf("# scripts/lat_probe.hip: one wavefront alone on the chip, shader clocks per operation (%d repetitions)\n", REP);
     for (int i = 0; i < 10; i++) printf("%-58s %8.1f clocks\n", names[i], (double)h[i] / per[i]);
+    double acc3[3];
+    hipMemcpy(acc3, out + 64, sizeof(acc3), hipMemcpyDeviceToHost);
+    printf("v_rsq_f64 max relative error %.2e; after one Newton step %.2e; after two %.2e\n", acc3[0], acc3[1], acc3[2]);
     return 0;
 }

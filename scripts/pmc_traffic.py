@@ -28,6 +28,7 @@ dw, vw = load(sys.argv[2], 'WRITE_SIZE')
 B, iters = int(sys.argv[3]), float(sys.argv[4])
 label = sys.argv[6] if len(sys.argv) > 6 else 'C1 state after 5 closed-loop steps, N=30'
 kname = sys.argv[7] if len(sys.argv) > 7 else 'k_qp_ipm<6,6>'
+key = sys.argv[8] if len(sys.argv) > 8 else 'k_qp_ipm'       # k_qp_ipm (a wavefront per two instances) or k_qp_ipm_wg (a workgroup per instance)
 half = lambda v: v[len(v) // 2:]      # the steady-state launches (qp_bench: identical inputs, repeated)
 mean = lambda v: sum(v) / len(v)
 out = {'workload': 'scripts/qp_bench.py: %s, B=%d, identical launches, mean %.2f IPM iterations' % (label, B, iters),
@@ -42,8 +43,8 @@ for k in [k_ for k_ in sorted(vf) if k_ in vw and (k_.startswith('k_qp') or k_.s
               'traffic_bytes_per_launch': byt, 'avg_duration_ms': dur * 1e3, 'traffic_GBps': byt / dur / 1e9}
 out['kernel'] = kname
 out['instances'], out['mean_iterations'] = B, iters
-out['traffic_bytes_per_launch'] = out['k_qp_ipm']['traffic_bytes_per_launch']
-out['bytes_per_instance_iteration'] = out['k_qp_ipm']['traffic_bytes_per_launch'] / (B * iters)
-out['traffic_GBps_in_pmc_run'] = out['k_qp_ipm']['traffic_GBps']
+out['traffic_bytes_per_launch'] = out[key]['traffic_bytes_per_launch']
+out['bytes_per_instance_iteration'] = out[key]['traffic_bytes_per_launch'] / (B * iters)
+out['traffic_GBps_in_pmc_run'] = out[key]['traffic_GBps']
 json.dump(out, open(sys.argv[5], 'w'), indent=1)
 print(json.dumps(out, indent=1))
