@@ -15,6 +15,7 @@ par, prob, net = bench.build_problem()
 if os.environ.get('SMPC_MAXIT'):
     prob.desc.qp_max_iter = int(os.environ['SMPC_MAXIT'])
 s = BatchedOcpSolver(prob, net)
+s.set_qp_mode('throughput')      # (k_qp_ipm's phases; the latency form, which the engine would pick below 512 instances, has scripts/qp_wg_phase_profile.py)
 B = int(os.environ.get('SMPC_B', '4096'))
 x0 = bench.initial_states(s, prob, B, 0)
 N = prob.N
