@@ -17,9 +17,13 @@
 // factor blocks, the defects, a1 / a2 and the roll-out in LDS: no HBM round trip sits on their chains any more.
 // SAME algorithm, SAME workspace records (written by k_stage_build / k_qp_setup, QpLayout) and the same per-row arithmetic
 // (qp_row_dir / qp_row_coeff of kernel_qp.hpp) as k_qp_ipm; only the order of a few sums differs (the x-x block is assembled before
-// the recursion instead of inside the P update; complementarity sums are taken per half-wave, then over half-waves), so the two
-// kernels agree to rounding, iterate for iterate (tests/test_gpu_parity.py::test_qp_kernels_agree).
-// The engine picks per launch (engine.hip: qp_wg_max_batch): this form for small batches, k_qp_ipm for throughput.
+// the recursion instead of inside the P update, [W | w]^T [W | w] comes from the f64 MFMA, complementarity sums are taken in eight
+// groups of stages), so the two kernels agree to rounding, iterate for iterate (tests/test_gpu_parity.py::test_qp_kernels_agree).
+// What bounds ONE wavefront is its instruction count -- one instruction per ~5 clocks whatever it is, an LDS hand-off 83 clocks, a
+// dependent f64 MFMA 80 (scripts/lat_probe.hip, profiles/r06_lat_probe.txt) -- so the recursions are written for few instructions:
+// lane-dependent addresses formed once, reads batched behind one wait (hold_n), in-place updates, zeros stored instead of masks.
+// The engine picks per launch (engine.hip: qp_wg_choice; smpc_set_qp_mode): this form up to 512 instances, k_qp_ipm for throughput.
+// DESIGN.md section 4c has the measurements (170 k clocks per IPM iteration of a lone instance against k_qp_ipm's 447 k).
 // Reference: controller.py:97-110, 136-167 (the QP HPIPM solves inside acados' RTI step).
 #pragma once
 #include "kernel_qp.hpp"
@@ -131,15 +135,7 @@ template <int N> __device__ __forceinline__ void hold_n(double (&a)[N]) {
     else if constexpr (N == 27) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]), "+v"(a[24]), "+v"(a[25]), "+v"(a[26]));
     else if constexpr (N == 28) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]), "+v"(a[16]), "+v"(a[17]), "+v"(a[18]), "+v"(a[19]), "+v"(a[20]), "+v"(a[21]), "+v"(a[22]), "+v"(a[23]), "+v"(a[24]), "+v"(a[25]), "+v"(a[26]), "+v"(a[27]));
 }
-// a double of lane `lane` for every lane (v_readlane_b32 x 2; the index is a constant): a six-vector that lives on six lanes reaches the
-// whole wavefront in a dozen scalar moves, without a round trip through LDS
-__device__ __forceinline__ double rdlane(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-// One workgroup of NHW half-wavefronts per instance.  `list` (optional): the instances to solve (grid-stride over *list_n entries);
-// without it block b solves instance b.
+// One workgroup of NHW half-wavefronts per instance: block b solves instance b.
 #ifndef QP_WG_WAVES_PER_EU
 #define QP_WG_WAVES_PER_EU 1
 #endif
