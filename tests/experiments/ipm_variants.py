@@ -4,6 +4,8 @@ solve in units of one full iteration's workspace traffic (B1 + F1 = 0.64, B2 + F
 iteration), the mean of the per-step maxima (what sets a launch's duration), failed solves and the deviation of
 the closed-loop trajectory from the baseline's.
 Needs the experiment knobs in the oracle:  git apply tests/experiments/ipm_variants_oracle_patch.diff && make -C oracle
+(the patch was cut against oracle/smpc_oracle.cpp of commit 671f866; the stall exit's total count, commit 1b9877b, came after it: check that
+file out of 671f866 first, or merge hunk 8 by hand -- round 6's tests/experiments/gondzio_oracle_patch.diff applies to the current oracle)
 (and `git checkout oracle/smpc_oracle.cpp && make -C oracle` afterwards: the committed oracle restates the engine's algorithm only).
 usage: python tests/experiments/ipm_variants.py [problem: st | constraint_everywhere | fr7 | ...] [B] [steps]
 
