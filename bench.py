@@ -404,7 +404,9 @@ def main():
     N = prob.N
     # (up to 512 instances the engine launches the latency form of the QP solve, a workgroup per instance: its launches have no tail
     #  worth overlapping, and one launch over all instances lets the engine see the whole batch when it picks the form)
-    S = 1 if B <= 512 else max(1, min(args.streams, B // 256 or 1))
+    # (up to 1024: two launches of up to 512 workgroups, the second one's starting as the first one's retire -- measured 1.65 ms per step
+    #  against 1.80 with three sub-batches and 2.05 with one launch of 1024)
+    S = 1 if B <= 512 else (min(2, args.streams) if B <= 1024 else max(1, min(args.streams, B // 256 or 1)))
 
     t = lambda a, dt=torch.float64: torch.tensor(a, dtype=dt, device=dev)
 
