@@ -615,7 +615,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     constexpr int NRC_MAX = NQ + MR_MAX + 1;
     static_assert(MRT < 0 || NX + NRC_MAX <= NL, "one lane per constraint row");
     static_assert(KS <= NL, "one lane per column of [G | rho | I]");
+#ifndef QP_P_INPLACE
+#define QP_P_INPLACE 0      // (measured, round 6: the eighth 7-DoF wavefront it buys makes C4 SLOWER, 20.82 -> 21.31 ms per step)
+#endif
+    constexpr bool P_INPLACE = QP_P_INPLACE != 0;
     constexpr int NTRI_U = NQ * (NQ + 1) / 2, NTRI_X = NX * (NX + 1) / 2;
+    // first index of the q-q corner's elements in the x-x index table (below): they need the cost Hessian and the collision rows
+    constexpr int TRI_Q0 = P_INPLACE ? NTRI_X - NTRI_U : 0;
     constexpr int IMG_MAX = NZ * NQP + NQ * MRP_MAX + NX + qp_even_c(NQ * NQ) + NZP + NX + 4;
     constexpr int IMG_PF = (IMG_MAX / 2 + 31) / 32;
     constexpr int CST_MAX = NRC_MAX * NZP;                                       // row-major image of the general rows in LDS
@@ -655,7 +661,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
     // [image | D | E | -- buffers of the factorisation sweep only: TD GD Lambda G Wt P P -- | vectors]
     constexpr int O_D = IMG_MAX, O_E = O_D + NL, O_TD = O_E + NL, O_GD = O_TD + NZ * NQP, O_LAM = O_GD + NQ * MRP_MAX,
                   O_G = O_LAM + qp_even_c(NQ * NQ), O_WT = O_G + NQ * WS2, O_PA = O_WT + (NX + 1) * NQP,
-                  O_PB2 = O_PA + NX * NX, O_PVA = O_PB2 + NX * NX, O_PVB = O_PVA + NX, O_PB = O_PVB + NX,
+                  O_PB2 = O_PA + (P_INPLACE ? 0 : NX * NX),      // (P_k is built over P_{k+1}: see the index table below)
+                  O_PEND = O_PB2 + NX * NX, O_STG = O_TD + CST_MAX + 2 * NWP,   // (the forward sweeps stage their blocks over the B1-only buffers)
+                  O_PVA = O_PEND > O_STG ? O_PEND : O_STG, O_PVB = O_PVA + NX, O_PB = O_PVB + NX,
                   O_ZU = O_PB + NX, O_XB = O_ZU + NQP, O_RHO = O_XB + 2 * NX, O_WV = O_RHO + NQP, HALF_D = O_WV + NQP;
     __shared__ __attribute__((aligned(16))) double smem[2 * HALF_D];
     __shared__ unsigned char triUi[NTRI_U], triUj[NTRI_U], triXi[NTRI_X], triXj[NTRI_X];
@@ -694,12 +702,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
         triUi[e] = (unsigned char)i;
         triUj[e] = (unsigned char)(i + rem);
     }
-    // upper triangle of the x-x block, the q-q corner (j < NQ) first: those NTRI_U <= 32 elements then all sit in the first pass
-    // of the loops over it, and the other passes skip what only the corner needs (cost Hessian, collision rows)
-    static_assert(NTRI_U <= 32, "the q-q corner fits the first pass");
+    // Upper triangle of the x-x block.  Default (QP_P_INPLACE=0): the q-q corner first, P ping-ponged between two buffers.  With
+    // -DQP_P_INPLACE=1 the table is ordered so that P_k can be built OVER P_{k+1} (one P buffer instead of two: 1.5 KB of LDS per
+    // half-wave at 7-DoF, 18.4 instead of 21.6 KB per block, i.e. the eighth wavefront per CU -- built and measured in round 6, parity
+    // green, and slower in C4's loop, so not the default): element (i, j) of P_k reads entries (i, j), (i, j - NQ), (i - NQ, j),
+    // (i - NQ, j - NQ) of P_{k+1} (A^T P A in closed form), i.e. its own and entries of blocks "below" its own in the order
+    // v-v > q-v > q-q.  With the v-v block first, then q-v, then the q-q corner, a pass only ever overwrites entries that no later pass
+    // reads; inside a pass every read is issued and waited for before the first write (hold_rows4).  The corner's elements -- the only
+    // ones that need the cost Hessian and the collision rows -- are the table's last NTRI_U.
+    static_assert(NTRI_U <= 32, "the v-v block (same size as the q-q corner) fits the first pass");
     for (int e = hl; e < NTRI_X; e += 32) {
         int i = 0, j;
-        if (e < NTRI_U) {
+        if (P_INPLACE) {
+            if (e < NTRI_U) {                       // v-v, rows NQ .. NX-1
+                int rem = e;
+                while (rem >= NQ - i) { rem -= NQ - i; i++; }
+                j = NQ + i + rem;
+                i += NQ;
+            } else if (e < NTRI_U + NQ * NQ) {      // q-v: the full NQ x NQ block
+                const int t = e - NTRI_U;
+                i = t / NQ;
+                j = NQ + t - i * NQ;
+            } else {                                // q-q corner
+                int rem = e - NTRI_U - NQ * NQ;
+                while (rem >= NQ - i) { rem -= NQ - i; i++; }
+                j = i + rem;
+            }
+        } else if (e < NTRI_U) {
             int rem = e;
             while (rem >= NQ - i) { rem -= NQ - i; i++; }
             j = i + rem;
@@ -1001,7 +1030,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                     for (int t = 0; t < (NTRI_X + 31) / 32; t++) {
                         const int el = min(hl + 32 * t, NTRI_X - 1);
                         const int ix = triXi[el], jx = triXj[el];
-                        const double a = hxx_elem(ix, jx, 32 * t < NTRI_U);
+                        const double a = hxx_elem(ix, jx, 32 * (t + 1) > TRI_Q0 && 32 * t < TRI_Q0 + NTRI_U);
                         Pn[ix * NX + jx] = a;
                         Pn[jx * NX + ix] = a;
                     }
@@ -1117,7 +1146,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                                 a = (s0 + s1) - (w0 + w1);
                             }
                             a = fma(sc[0] * sc[2], sc[1], a);
-                            if (32 * t < NTRI_U) {   // (the q-q corner: first pass only, see the index table)
+                            if (32 * (t + 1) > TRI_Q0 && 32 * t < TRI_Q0 + NTRI_U) {   // (the passes that hold elements of the q-q corner, see the index table)
                                 const int iq = min(i, NQ - 1), jq = min(j, NQ - 1);
                                 const double qq = sHQQ[iq * NQ + jq] + pdot(sGT + iq * MRP, sGD + jq * MRP, MRP >> 1);
                                 a += j < NQ ? qq : 0.0;
@@ -1143,7 +1172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(QP_WAVES_PER
                 QPT(4);
                 lds_fence();
                 if (last || k > 0) {
-                    double* t1 = Pc; Pc = Pn; Pn = t1;
+                    if (!P_INPLACE) { double* t1 = Pc; Pc = Pn; Pn = t1; }
                     double* t2 = pvc; pvc = pvn; pvn = t2;
                 }
                 QPT(5);
