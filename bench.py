@@ -308,8 +308,8 @@ def main():
                     help='1: replay each sub-batch step as a captured hipGraph (one host launch per sub-batch and step instead of '
                          '~25; measured on one GPU: no gain, DESIGN.md section 7 -- kept for A/B runs on a node whose ranks share '
                          'the host; legal under torch.distributed: the log slot comes from a device-side step counter)')
-    ap.add_argument('--streams', type=int, default=3,
-                    help='sub-batches per GPU, each on its own HIP stream: independent instances, so the sub-batches advance '
+    ap.add_argument('--streams', type=int, default=None,
+                    help='sub-batches per GPU (default: 3 above 1024 instances, 2 up to 1024, 1 up to 512), each on its own HIP stream: independent instances, so the sub-batches advance '
                          'independently and the long tail of one QP launch overlaps the bulk of another (round 4, DESIGN.md '
                          'section 8: 2 / 3 / 4 / 5 / 6 streams = 3.15 / 2.92 / 3.17 / 3.22 / 3.14 ms per step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -406,7 +406,7 @@ def main():
     #  worth overlapping, and one launch over all instances lets the engine see the whole batch when it picks the form)
     # (up to 1024: two launches of up to 512 workgroups, the second one's starting as the first one's retire -- measured 1.65 ms per step
     #  against 1.80 with three sub-batches and 2.05 with one launch of 1024)
-    S = 1 if B <= 512 else (min(2, args.streams) if B <= 1024 else max(1, min(args.streams, B // 256 or 1)))
+    S = (1 if B <= 512 else (2 if B <= 1024 else max(1, min(3, B // 256 or 1)))) if args.streams is None else max(1, min(args.streams, B))
 
     t = lambda a, dt=torch.float64: torch.tensor(a, dtype=dt, device=dev)
 
