@@ -53,6 +53,7 @@ struct smpc_handle {
     int qp_mode = -2;             // smpc_set_qp_mode: SMPC_QP_AUTO / _THROUGHPUT / _LATENCY; -2 = not set (the process default, SMPC_QP_WG)
     double* d_hrec = nullptr;     // k_qp_ipm_wg only: the stages' P-independent blocks, [B][N+1][HRecLayout::SIZE] (allocated on first use)
     size_t hrec_doubles = 0;
+    size_t wg_lds_set[2] = {0, 0};    // dynamic-LDS limit already raised for this handle's instantiation of k_qp_ipm_wg (8 / 4 half-waves)
     int32_t *d_order = nullptr, *d_last_it = nullptr;  // longest-first dispatch order from the previous call's iterations
     int order_B = 0;                                   // batch size d_last_it is valid for (0 = none yet)
     int32_t* d_ord_hist = nullptr;                     // [256] histogram of d_last_it (k_qp_ipm) | [256] bin cursors | ticket (k_order_by_iters)
@@ -525,11 +526,12 @@ int launch_qp_wg(smpc_handle* h, int B, const double* x0, const double* xg, cons
     const size_t lds = (size_t)WgLds<NQ>(h->N, h->desc.n_rows, NHW).total * sizeof(double);
 #define SMPC_WG_LAUNCH(MR_)                                                                                                        \
     do {                                                                                                                           \
-        static size_t attr_set = 0;                                                                                                \
-        if (lds > attr_set) {                                                                                                      \
+        if (!h->wg_lds_set[NHW == 8 ? 0 : 1]) {                                                                                   \
+            /* (once per handle = per device, nq and row count: the kernel may use a whole CU's LDS -- always the same value, so a    \
+             *  handle with a short horizon never lowers the limit under one with a long horizon) */                               \
             HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_qp_ipm_wg<NQ, MR_, NHW>),                               \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
-            attr_set = lds;                                                                                                        \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)QP_WG_LDS_LIMIT));                      \
+            h->wg_lds_set[NHW == 8 ? 0 : 1] = QP_WG_LDS_LIMIT;                                                                     \
         }                                                                                                                          \
         hipLaunchKernelGGL((k_qp_ipm_wg<NQ, MR_, NHW>), dim3(B), dim3(32 * NHW), lds, h->stream, h->d_desc, B, h->N, x0, xg,         \
                            ug, h->d_ws, h->d_hrec, xo, uo, st, it, h->d_last_it, h->d_active, h->d_ord_hist);                      \
