@@ -54,8 +54,8 @@ template <int NQ> struct WgLds {
     static constexpr int LCOL = NX + 2, FS = qp_even_c(NX + 2 + NQ), NFW = NQ * FS;
     static constexpr int NZS = NZP + 2;        // roll-out record of a stage: [u | x | two cells that absorb the stores of idle lanes]
     int MRP, NRC, SCR_A, SCR_D, CST;
-    int o_fac, o_a12, o_scrd, o_z, o_wc, o_b, o_bf, o_seq;
-    int s_P, s_pv, s_lam, s_G, s_R, s_V, s_red, s_flag;
+    int o_fac, o_a12, o_scrd, o_scra2, o_z, o_wc, o_b, o_bf, o_seq;
+    int s_P, s_pv, s_lam, s_G, s_R, s_V, s_red, s_part, s_flag;
     int total;
     // scratch of a half-wave in phase A: [image | D | E | TD | GD]; in phases D / G: [D | E | b, scalars | row-major general rows | dump]
     int a_D, a_E, a_TD, a_GD;
@@ -70,11 +70,12 @@ template <int NQ> struct WgLds {
         d_D = 0; d_E = 32; d_BS = 64; d_CST = d_BS + qp_even_c(NX + 4); d_DUMP = d_CST + qp_even_c(CST);
         SCR_D = d_DUMP + 2;
         const int n1 = N + 1;
-        const int r0 = n1 * (NFW + 2 * NZP), ra = NHW * SCR_A;
+        const int r0 = n1 * (NFW + 2 * NZP), ra = (NHW < 2 ? NHW : 2) * SCR_A;     // (half-waves 0 and 1: phase-A scratch over the dead factor blocks)
         o_fac = 0;
         o_a12 = n1 * NFW;
         o_scrd = r0 > ra ? r0 : ra;
-        o_z = o_scrd + NHW * SCR_D;
+        o_scra2 = o_scrd + NHW * SCR_D;            // phase-A scratch of the half-waves 2 .. NHW-1, which assemble a chunk of stages WHILE
+        o_z = o_scra2 + (NHW > 2 ? NHW - 2 : 0) * SCR_A;   // wavefront 0 factorises the chunk above it (so not over the factor blocks)
         o_wc = o_z + (n1 + 1) * NZS;
         o_b = o_wc + n1 * NQP;
         o_bf = o_b + n1 * NX;
@@ -86,6 +87,7 @@ template <int NQ> struct WgLds {
         s_G = s; s += NQ * WS2;
         s_R = s; s += NQP + 2;               // rho of a stage (hand-off inside the roll-outs / the corrector's recursion) + dump
         s_V = s; s += NQP + 2;               // L^-1 rho of the corrector's recursion + dump
+        s_part = s; s += qp_even_c(n1);      // complementarity sum of every stage (phase A)
         s_red = s; s += 4 * 8;               // (eight groups whatever the workgroup size: block_reduce)
         s_flag = s; s += 2;
         total = s;
@@ -100,6 +102,9 @@ __device__ unsigned long long g_wg_prof[16];
 #endif
 
 
+#ifndef QP_WG_CHUNK
+#define QP_WG_CHUNK 8      // stages per step of the assembly / factorisation overlap (phases A and B)
+#endif
 typedef double v4d __attribute__((ext_vector_type(4)));
 // "These N values are needed HERE": one empty asm that lists them all -- the compiler then issues every load behind them before this
 // point and waits once (kernel_qp.hpp: hold_rows2 / hold_rows4; left alone it sinks each LDS read next to its use, and a lone wavefront
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     double* const sG = dsm + Ls.s_G;
     double* const sRed = dsm + Ls.s_red;
     double* const sFlag = dsm + Ls.s_flag;
+    double* const sPart = dsm + Ls.s_part;
 
     auto pdot = [&](const double* a, const double* bb, int n2) -> double {
         const dbl2* a2 = reinterpret_cast<const dbl2*>(a);
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     // the workgroup's size: stage k belongs to group k mod 8 (a lane adds its stages of a group in increasing order, then the 32
     // lanes, then the groups 0 .. 7), so a workgroup of 4 half-waves, which owns two groups per half-wave, gets the bits of one of 8.
     constexpr int NVG = 8, GPH = NVG / NHW;        // groups, groups per half-wave
-    static_assert(NVG % NHW == 0 && NHW <= NVG, "half-waves per workgroup: 8, 4, 2 or 1");
+    static_assert(NVG % NHW == 0 && NHW <= NVG && NHW >= 4, "half-waves per workgroup: 8 or 4 (wavefront 0 runs the recursions, the others assemble beside it)");
     auto block_reduce = [&](double& vmax, double (&s1)[GPH], double (&s2)[GPH]) {
         vmax = half_max(vmax);
 #pragma unroll
@@ -394,10 +400,13 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     for (it = 0; it < max_iter; it++) {
         if (mu <= tol && rho_lin * R0 <= tol_r) { st_code = 0; break; }
 
-        // =============== phase A: rows + P-independent blocks of every stage ==============================================
-        double mu_new[GPH] = {};
-        {
-            double* const scr = dsm + hw * Ls.SCR_A;       // (over the factor blocks and a1 / a2 of the previous iteration: dead)
+        // =============== phases A and B, overlapped by chunks of stages =====================================================
+        // A (rows + the stage's P-independent blocks, any half-wave, any order) feeds B (the Riccati recursion on wavefront 0, stage N
+        // down to 0).  All half-waves assemble the top chunk of QP_WG_CHUNK stages; from then on wavefront 0 factorises a chunk WHILE the
+        // half-waves 2 .. NHW-1 assemble the one below it, a workgroup barrier between steps (no flags, no spinning).  With two
+        // wavefronts per workgroup the two run at the same rate (8 stages of B ~ 20 k clocks, 8 stages of A on two half-waves ~ 20 k) and
+        // the assembly all but disappears behind the recursion: A + B 118 k -> ~90 k clocks; with four wavefronts 98 k -> ~85 k.
+        auto phaseA_stage = [&](int k, double* const scr) {
             double* const sIMG = scr;
             double* const sTT = sIMG + Ly.iTT;
             double* const sGT = sIMG + Ly.iGT;
@@ -410,37 +419,31 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
             double* const sE = scr + Ls.a_E;
             double* const sTD = scr + Ls.a_TD;
             double* const sGD = scr + Ls.a_GD;
-            // (the records of this half-wave's NEXT stage are requested as soon as the registers of this one are free: a stage-round
-            //  otherwise starts with a full HBM / L2 latency, 500-800 clocks of the ~5000 a round takes)
-            dbl2 img[IMG_PF], pr0, pr1, pr2, pslb;
-            double pcza, pczn, pz, pzn;
-            auto load_a = [&](int k) {
-                const double* w = ws + (size_t)k * Ly.stride;
-                const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
-#pragma unroll
-                for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
-                pr0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr]; pr1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr];
-                pr2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
-                pcza = w[Ly.oCZA + hr]; pczn = w[Ly.oCZN + hr];
-                pslb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
-                pz = w[Ly.oZ + hz]; pzn = w[Ly.oZN + hz];
-            };
-            load_a(min(hw, N));
-            for (int k = hw; k <= N; k += NHW) {
+            double mu_part = 0.0;
+            {
                 const bool last = (k == N);
                 double* w = ws + (size_t)k * Ly.stride;
                 double* hk = hrec + (size_t)k * HR::SIZE;
+                dbl2 img[IMG_PF];
+                {
+                    const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
+#pragma unroll
+                    for (int j = 0; j < IMG_PF; j++) img[j] = s2[min(hl + 32 * j, img_n2 - 1)];
+                }
+                QpRow rs;
+                {
+                    const dbl2 r0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr], r1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr],
+                               r2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
+                    rs.lo = r0.x; rs.hi = r0.y; rs.tl = r1.x; rs.tu = r1.y; rs.ll = r2.x; rs.lu = r2.y;
+                }
+                const double czar = w[Ly.oCZA + hr], cznr = w[Ly.oCZN + hr], znc = w[Ly.oZN + hz];
+                const dbl2 slb = *reinterpret_cast<const dbl2*>(w + Ly.oSL);
+                double zc = w[Ly.oZ + hz];
                 {
                     dbl2* d2 = reinterpret_cast<dbl2*>(sIMG);
 #pragma unroll
                     for (int j = 0; j < IMG_PF; j++) d2[min(hl + 32 * j, img_n2 - 1)] = img[j];
                 }
-                QpRow rs;
-                rs.lo = pr0.x; rs.hi = pr0.y; rs.tl = pr1.x; rs.tu = pr1.y; rs.ll = pr2.x; rs.lu = pr2.y;
-                const double czar = pcza, cznr = pczn, znc = pzn;
-                const dbl2 slb = pslb;
-                double zc = pz;
-                load_a(min(k + NHW, N));
                 const double wsoft = slb.x;
                 {
                     const bool soft = soft_lane && wsoft >= 0.0;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                     double Dr;
                     sE[hr] = qp_row_coeff(rs, soft, wsoft, 0.0, 0.0, 0.0, &Dr);
                     sD[hr] = Dr;
-                    add_to_group(mu_new, k, row_live ? qp_row_comp(rs, soft, wsoft) : 0.0);
+                    mu_part = row_live ? qp_row_comp(rs, soft, wsoft) : 0.0;
                 }
                 zc += alpha * (znc - zc);
                 w[Ly.oZ + hz] = zc;
@@ -556,25 +559,14 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 }
                 lds_fence();      // (the next stage of this half-wave overwrites the scratch)
             }
-        }
-        if (pending) {
-            double dummy_m = 0.0, dummy_s[GPH] = {};
-            block_reduce(dummy_m, mu_new, dummy_s);      // (ends with a barrier: phase A's stores are visible to wavefront 0)
-            mu = mu_new[0] * inv_m;
-            pending = false;
-            if (!(mu == mu)) { st_code = 4; break; }
-        } else {
-            __syncthreads();
-        }
-        WGT(0);
-
-        // =============== phase B: Riccati recursion (wavefront 0, all 64 lanes) ============================================
-        // Per stage two LDS hand-offs: [Lambda | G | rho] -> Cholesky (registers, every lane) + one column of [W | w | L^-1] per lane ->
-        // [W | w]^T [W | w] on the f64 MFMA, straight from the columns' registers -> P_k, p_k -> LDS (in place).  The stage's H record
-        // comes from HBM / L2 into the registers of the lanes that use it, one stage ahead.
-        if (seq) {
+            // the stage's share of sum(lambda t): summed over its rows here, over the stages in stage order at the end (the same bits
+            // whatever half-wave took the stage)
+            mu_part = half_sum(mu_part);
+            if (hl == 0) sPart[k] = mu_part;
+        };
+        double dmin = 1.0;
+        auto riccati_chunk = [&](int k_hi, int k_lo) {
             double Lr[NQ][NQ], Linv[NQ];
-            double dmin = 1.0;
             double hA[2], hX[XR], hG, hGx;
             auto load_h = [&](int k) {
                 const double* hk = hrec + (size_t)k * HR::SIZE;
@@ -585,20 +577,24 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 hG = hk[HR::oGH + hz];
                 hGx = hk[HR::oGH + NU + min(lc, NX - 1)];
             };
-            // P_N = the x-x block, p_N = the x part of the gradient
-            load_h(N);
+            int k = k_hi;
+            load_h(k);
+            if (k == N) {
+                // P_N = the x-x block, p_N = the x part of the gradient
 #pragma unroll
-            for (int r = 0; r < XR; r++) dsm[lpd[r]] = hX[r];
-            dsm[Ls.s_pv + pv_dst_e] = hG;
-            load_h(N > 0 ? N - 1 : 0);
-            lds_fence();
-            for (int k = N - 1; k >= 0; k--) {
+                for (int r = 0; r < XR; r++) dsm[lpd[r]] = hX[r];
+                dsm[Ls.s_pv + pv_dst_e] = hG;
+                lds_fence();
+                k = N - 1;
+                if (k >= k_lo) load_h(k);
+            }
+            for (; k >= k_lo; k--) {
                 double* const fk = sFac + k * NFW;
                 const double a0 = hA[0], a1 = hA[1], gh = hG, ghx = hGx;
                 double hx[XR];
 #pragma unroll
                 for (int r = 0; r < XR; r++) hx[r] = hX[r];
-                load_h(k > 0 ? k - 1 : 0);
+                if (k > k_lo) load_h(k - 1);      // (the chunk below is still being assembled: its first record is fetched after the barrier)
                 const bool bfl = sBf[k] != 0.0;
                 asm volatile("; WGMARK B_LG_BEGIN");
                 // Lambda = Huu + B^T P B (triangle, mirrored) and G = Hux + B^T P A: one formula, four entries of P with this lane's
@@ -710,9 +706,32 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 WGT(10);
             }
             if (!(half_min(dmin) > 0.0) && hl == 0) sFlag[0] = 1.0;
+        };
+        {
+            constexpr int CH = QP_WG_CHUNK;
+            double* const scr_a = hw < 2 ? dsm + hw * Ls.SCR_A : dsm + Ls.o_scra2 + (hw - 2) * Ls.SCR_A;
+            int k_hi = N, k_lo = max(N - CH + 1, 0);
+            for (int k = k_hi - hw; k >= k_lo; k -= NHW) phaseA_stage(k, scr_a);
+            __syncthreads();
+            WGT(0);
+            for (;;) {
+                const int n_hi = k_lo - 1, n_lo = max(n_hi - CH + 1, 0);
+                if (seq) riccati_chunk(k_hi, k_lo);
+                else if (n_hi >= 0)
+                    for (int k = n_hi - (hw - 2); k >= n_lo; k -= NHW - 2) phaseA_stage(k, scr_a);
+                __syncthreads();
+                if (n_hi < 0) break;
+                k_hi = n_hi; k_lo = n_lo;
+            }
         }
-        __syncthreads();
         WGT(1);
+        if (pending) {
+            double acc = 0.0;
+            for (int k = 0; k <= N; k++) acc += sPart[k];
+            mu = acc * inv_m;
+            pending = false;
+            if (!(mu == mu)) { st_code = 4; break; }
+        }
         if (sFlag[0] != 0.0) { st_code = 4; pending = false; break; }
 
         // roll-out through the factor blocks: z_k = [u_k | x_k] for every stage (wavefront 0).  Every operand of a stage is read in one
