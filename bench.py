@@ -477,6 +477,12 @@ def main():
         off += len(gids)
     solvers = [sb.solver for sb in subs]
     S = len(subs)
+    # The form of the QP solve (smpc_set_qp_mode): a handle picks it from ITS launch size, the bench from the rank's whole batch -- the
+    # latency form (a workgroup per instance) while the sub-batches are at most 512 instances (1536 per GPU), the throughput form above
+    # (three sub-batches of 683 on the latency form: 2.81 ms per step against 2.60)
+    qp_form = 'latency' if max(sb.n for sb in subs) <= 512 and B <= 1536 else 'throughput'
+    for sv in solvers + [probe_sv]:
+        sv.set_qp_mode(qp_form)
     sizes_all = [int(sum(len(v) for v in partition(r)[0].values())) for r in range(world)]
     if cfg == 'c3' and args.scaling == 'weak':
         B_total = int(sum(sizes_all))        # (the horizon groups do not divide evenly: the first ranks take the remainders)
@@ -645,6 +651,7 @@ def main():
     Bp = int(sum(sb.n for sb in psubs))
     if rank == 0:
         sv = probe_sv if probe_sv.N == probe_N else BatchedOcpSolver(prob, net, device=local)
+        sv.set_qp_mode(qp_form)
         st_ = torch.cuda.ExternalStream(sv.L.smpc_stream(sv.h), device=dev)
         with torch.cuda.stream(st_):
             xs = torch.cat([sb.x_sim for sb in psubs]); xgf = torch.cat([sb.ctrl.x_guess for sb in psubs])
@@ -670,7 +677,7 @@ def main():
         alg = algorithmic_bytes(prob.nq, N) * Bp
         ach = alg / acc[5] / 1e9
         # the form of the QP solve the engine picks for a launch of this size (engine.hip: qp_wg_choice; smpc_set_qp_mode)
-        qp_kernel = 'k_qp_ipm_wg' if Bp <= 512 else 'k_qp_ipm'
+        qp_kernel = 'k_qp_ipm_wg' if qp_form == 'latency' else 'k_qp_ipm'
         # FLOP fractions: algorithmic flops of the launch / its HIP-event duration / peak
         nh = prob.nq + prob.desc.n_rows + 1
         qp_fl = qp_flops_per_iteration(prob.nq, N, nh) * it_probe * Bp
@@ -798,7 +805,7 @@ def main():
             'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workload, 'name': cfg,
                        'batch_per_gpu': B, 'batch_total': B_total, 'horizon': sorted({sb.N for sb in subs}) if cfg == 'c3' else N,
-                       'controller': controller, 'streams_per_gpu': S,
+                       'controller': controller, 'streams_per_gpu': S, 'qp_form': qp_form,
                        'hip_graphs': bool(subs[0].graph is not None),
                        'batched_steps_per_s': args.steps / elapsed, 'mean_ipm_iterations': mean_iter,
                        'failed_instance_steps': fails},

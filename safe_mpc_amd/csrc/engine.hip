@@ -481,13 +481,16 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
 // k_qp_ipm_wg (kernel_qp_wg.hpp), the latency form of the interior-point solve -- one workgroup per instance: -1 (default) chosen by
 // batch size, 0 never, 1 whenever its LDS fits (SMPC_QP_WG; smpc_set_qp_mode per handle).  Built with 8 half-wavefronts per
 // workgroup (four wavefronts, one per SIMD: one workgroup per CU -- up to qp_wg_full_batch instances run in one round) and with 4
-// (two wavefronts: two workgroups per CU, the stage-parallel phases take twice the rounds -- up to qp_wg_max_batch instances).  Above
-// that k_qp_ipm's two instances per wavefront use the chip better (measured: DESIGN.md section 4c).
+// (two wavefronts: two workgroups per CU, the stage-parallel phases take twice the rounds -- 512 instances in one round, up to
+// qp_wg_max_batch = 1024 in one launch whose later workgroups start as the first ones retire: 1.86 ms per step against k_qp_ipm's 2.33 at
+// 1024, 2.29 against 2.43 at 1280, 2.61 against 2.51 at 1536).  Above that k_qp_ipm's two instances per wavefront use the chip better
+// (measured: DESIGN.md section 4c).  A handle only sees its own launch: a caller that spreads ONE batch over several handles should pick
+// the form from the total (bench.py does: the latency form up to 1536 instances per GPU in sub-batches of at most 512).
 #ifndef QP_WG_FULL_BATCH
 #define QP_WG_FULL_BATCH 256
 #endif
 #ifndef QP_WG_MAX_BATCH
-#define QP_WG_MAX_BATCH 512
+#define QP_WG_MAX_BATCH 1024
 #endif
 static int qp_wg_mode() {
     static const int v = [] { const char* e = getenv("SMPC_QP_WG"); return e ? atoi(e) : -1; }();
