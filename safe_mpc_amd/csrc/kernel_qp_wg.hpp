@@ -13,7 +13,8 @@
 //   E  wavefront 0: corrector costate (touches only LDS)
 //   F  wavefront 0: corrector roll-out
 //   G  stage-parallel: c.z+, ratio test, z+ -> workspace
-// with a workgroup barrier between phases and the step-length logic replicated on every lane.  The sequential phases keep the
+// with a workgroup barrier between phases and the step-length logic replicated on every lane; A and B overlap by chunks of eight
+// stages (wavefront 0 factorises a chunk while the other half-waves assemble the one below it).  The sequential phases keep the
 // factor blocks, the defects, a1 / a2 and the roll-out in LDS: no HBM round trip sits on their chains any more.
 // SAME algorithm, SAME workspace records (written by k_stage_build / k_qp_setup, QpLayout) and the same per-row arithmetic
 // (qp_row_dir / qp_row_coeff of kernel_qp.hpp) as k_qp_ipm; only the order of a few sums differs (the x-x block is assembled before
@@ -22,8 +23,8 @@
 // What bounds ONE wavefront is its instruction count -- one instruction per ~5 clocks whatever it is, an LDS hand-off 83 clocks, a
 // dependent f64 MFMA 80 (scripts/lat_probe.hip, profiles/r06_lat_probe.txt) -- so the recursions are written for few instructions:
 // lane-dependent addresses formed once, reads batched behind one wait (hold_n), in-place updates, zeros stored instead of masks.
-// The engine picks per launch (engine.hip: qp_wg_choice; smpc_set_qp_mode): this form up to 512 instances, k_qp_ipm for throughput.
-// DESIGN.md section 4c has the measurements (170 k clocks per IPM iteration of a lone instance against k_qp_ipm's 447 k).
+// The engine picks per launch (engine.hip: qp_wg_choice; smpc_set_qp_mode): this form up to 1024 instances, k_qp_ipm for throughput.
+// DESIGN.md section 4c has the measurements (156 k clocks per IPM iteration of a lone instance against k_qp_ipm's 447 k).
 // Reference: controller.py:97-110, 136-167 (the QP HPIPM solves inside acados' RTI step).
 #pragma once
 #include "kernel_qp.hpp"

@@ -20,7 +20,7 @@ bash scripts/prof_pmc.sh r06/pmc_wg wg > $O/pmc_wg.log 2>&1 && cp $O/pmc_wg/pmc_
 bash scripts/prof_pmc.sh r06/pmc_c4 c4 > $O/pmc_c4.log 2>&1 && cp $O/pmc_c4/pmc_traffic.json $O/pmc_traffic_c4.json
 # (the bench lines read profiles/r06_pmc_traffic*.json: make this session's files visible to them)
 cp $O/pmc_traffic.json $R/profiles/r06_pmc_traffic.json; cp $O/pmc_traffic_c4.json $R/profiles/r06_pmc_traffic_c4.json; cp $O/pmc_traffic_wg.json $R/profiles/r06_pmc_traffic_wg.json
-python3 scripts/latency_scaling.py --out-dir $O --tag r06 > $O/latency_scaling.log 2>&1
+python3 scripts/latency_scaling.py --out-dir $O --tag r06 --batches 4096,2048,1536,1024,512 > $O/latency_scaling.log 2>&1
 mv $O/r06_strong_scaling_proxy.json $O/strong_scaling_proxy.json; mv $O/r06_latency.json $O/latency.json
 cp $O/strong_scaling_proxy.json $R/profiles/r06_strong_scaling_proxy.json
 timeout -k 10 400 python3 bench.py > $O/bench.json 2> $O/bench.err
