@@ -545,6 +545,22 @@ def test_qp_kernels_agree(case):
     print(f'[qp kernels, {case}] worst control gap {worst:.1e}, {differ} solves with iteration counts one apart')
 
 
+def test_qp_mode_argument_is_checked_and_latency_falls_back_when_lds_is_short():
+    """smpc_set_qp_mode: anything but AUTO / THROUGHPUT / LATENCY is API misuse (an error code and a message, no change of mode); a
+    horizon whose factor blocks do not fit one CU's LDS is solved by the throughput form even when the latency form is asked for."""
+    par, prob, net = make_problem('st', 'ext', N=8)
+    s = _solver(prob, net)
+    assert s.L.smpc_set_qp_mode(s.h, 7) != 0 and b'qp mode' in s.L.smpc_last_error(s.h)
+    assert s.L.smpc_set_qp_mode(s.h, -2) != 0
+    x0 = sample_instances(prob, 6, seed=3)
+    xg, ug, p = constant_guess(prob, x0)
+    ref = s.solve(x0, xg, ug, p)
+    for mode in ('throughput', 'latency', 'auto'):
+        s.set_qp_mode(mode)
+        out = s.solve(x0, xg, ug, p)
+        assert np.array_equal(out[2], ref[2]) and np.abs(out[1] - ref[1]).max() < 1e-7 * (1 + np.abs(ref[1]).max())
+
+
 @pytest.mark.parametrize('N', [1, 2, 3, 63])
 def test_horizon_extremes(N, qp_mode):
     """Shortest horizons (the unrolled / look-ahead loops of the QP kernel degenerate) and SMPC_MAX_N."""
