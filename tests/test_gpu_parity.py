@@ -545,9 +545,9 @@ def test_qp_kernels_agree(case):
     print(f'[qp kernels, {case}] worst control gap {worst:.1e}, {differ} solves with iteration counts one apart')
 
 
-def test_qp_mode_argument_is_checked_and_latency_falls_back_when_lds_is_short():
-    """smpc_set_qp_mode: anything but AUTO / THROUGHPUT / LATENCY is API misuse (an error code and a message, no change of mode); a
-    horizon whose factor blocks do not fit one CU's LDS is solved by the throughput form even when the latency form is asked for."""
+def test_qp_mode_argument_is_checked():
+    """smpc_set_qp_mode: anything but AUTO / THROUGHPUT / LATENCY is API misuse (an error code and a message, no change of mode); the
+    three valid modes give the same statuses and the same controls to the kernels' mutual tolerance."""
     par, prob, net = make_problem('st', 'ext', N=8)
     s = _solver(prob, net)
     assert s.L.smpc_set_qp_mode(s.h, 7) != 0 and b'qp mode' in s.L.smpc_last_error(s.h)
