@@ -797,7 +797,7 @@ def main():
                 extra['strong_proxy'] = {'source': 'profiles/r06_strong_scaling_proxy.json (scripts/latency_scaling.py: bench.py --batch <per-GPU share> on one GPU; '
                                                    'instances are independent, one gather per rollout)',
                                          'ms_per_step_by_share': {str(r_['batch']): r_['ms_per_step'] for r_ in rows_},
-                                         'predicted_speedup_by_gpus': {str(r_['gpus_at_4096_total']): r_['predicted_strong_speedup'] for r_ in rows_}}
+                                         'predicted_speedup_by_gpus': {('%g' % r_['gpus_at_4096_total']): r_['predicted_strong_speedup'] for r_ in rows_}}
         line = {
             'metric': metric,
             'value': total / elapsed, 'unit': 'instance-steps/s', 'n_gpus': world, 'steps': args.steps,

@@ -42,7 +42,7 @@ def proxy(batches, extra_env=None):
         print('[proxy]', rows[-1], flush=True)
     t_full = rows[0]['ms_per_step']
     for r in rows:
-        r['gpus_at_4096_total'] = batches[0] // r['batch']
+        r['gpus_at_4096_total'] = round(batches[0] / r['batch'], 2)      # (1536 = the share on 2.67 GPUs: a point of the curve, not a node size)
         r['predicted_strong_speedup'] = t_full / r['ms_per_step']
         r['predicted_strong_efficiency'] = r['predicted_strong_speedup'] / r['gpus_at_4096_total']
     return rows
