@@ -482,10 +482,11 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
 // batch size, 0 never, 1 whenever its LDS fits (SMPC_QP_WG; smpc_set_qp_mode per handle).  Built with 8 half-wavefronts per
 // workgroup (four wavefronts, one per SIMD: one workgroup per CU -- up to qp_wg_full_batch instances run in one round) and with 4
 // (two wavefronts: two workgroups per CU, the stage-parallel phases take twice the rounds -- 512 instances in one round, up to
-// qp_wg_max_batch = 1024 in one launch whose later workgroups start as the first ones retire: 1.86 ms per step against k_qp_ipm's 2.33 at
-// 1024, 2.29 against 2.43 at 1280, 2.61 against 2.51 at 1536).  Above that k_qp_ipm's two instances per wavefront use the chip better
-// (measured: DESIGN.md section 4c).  A handle only sees its own launch: a caller that spreads ONE batch over several handles should pick
-// the form from the total (bench.py does: the latency form up to 1536 instances per GPU in sub-batches of at most 512).
+// qp_wg_max_batch = 1024 in one launch whose later workgroups start as the first ones retire).  Above that k_qp_ipm's two instances per
+// wavefront use the chip better (per step, latency form against k_qp_ipm: 1.08 ms against 2.16 at 512 instances, 1.45 against 2.27 at
+// 1024 as two sub-batches of 512, 2.13 against 2.46 at 1536 as three; from 2048 on k_qp_ipm wins -- DESIGN.md section 4c).  A handle
+// only sees its own launch: a caller that spreads ONE batch over several handles should pick the form from the total (bench.py does:
+// the latency form up to 1536 instances per GPU in sub-batches of at most 512).
 #ifndef QP_WG_FULL_BATCH
 #define QP_WG_FULL_BATCH 256
 #endif
