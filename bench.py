@@ -312,6 +312,9 @@ def main():
                     help='sub-batches per GPU (default: 3 above 1024 instances, 2 up to 1024, 1 up to 512), each on its own HIP stream: independent instances, so the sub-batches advance '
                          'independently and the long tail of one QP launch overlaps the bulk of another (round 4, DESIGN.md '
                          'section 8: 2 / 3 / 4 / 5 / 6 streams = 3.15 / 2.92 / 3.17 / 3.22 / 3.14 ms per step)')
+    ap.add_argument('--qp-form', choices=['auto', 'throughput', 'latency'], default='auto',
+                    help="form of the interior-point solve (smpc_set_qp_mode); auto: the latency form (a workgroup per instance) up to "
+                         "1536 instances per GPU in sub-batches of at most 512, the throughput form above -- the others are for A/B runs")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true', help='skip the one-instance latency measurement added to the C1 line')
     ap.add_argument('--noise', type=float, default=0.0,
@@ -481,6 +484,8 @@ def main():
     # latency form (a workgroup per instance) while the sub-batches are at most 512 instances (1536 per GPU), the throughput form above
     # (three sub-batches of 683 on the latency form: 2.81 ms per step against 2.60)
     qp_form = 'latency' if max(sb.n for sb in subs) <= 512 and B <= 1536 else 'throughput'
+    if args.qp_form != 'auto':
+        qp_form = args.qp_form
     for sv in solvers + [probe_sv]:
         sv.set_qp_mode(qp_form)
     sizes_all = [int(sum(len(v) for v in partition(r)[0].values())) for r in range(world)]
