@@ -54,6 +54,7 @@ template <int NQ> struct WgLds {
     // 16-byte pieces, and L^-1 carries its zeros (no masks in the recursions)
     static constexpr int LCOL = NX + 2, FS = qp_even_c(NX + 2 + NQ), NFW = NQ * FS;
     static constexpr int NZS = NZP + 2;        // roll-out record of a stage: [u | x | two cells that absorb the stores of idle lanes]
+    static constexpr int ACC = 8 * 32 * 2;     // accumulator cells of the row phases (aliased over the assembling half-waves' scratch)
     int MRP, NRC, SCR_A, SCR_D, CST;
     int o_fac, o_a12, o_scrd, o_scra2, o_z, o_wc, o_b, o_bf, o_seq;
     int s_P, s_pv, s_lam, s_G, s_R, s_V, s_red, s_part, s_flag;
@@ -76,7 +77,10 @@ template <int NQ> struct WgLds {
         o_a12 = n1 * NFW;
         o_scrd = r0 > ra ? r0 : ra;
         o_scra2 = o_scrd + NHW * SCR_D;            // phase-A scratch of the half-waves 2 .. NHW-1, which assemble a chunk of stages WHILE
-        o_z = o_scra2 + (NHW > 2 ? NHW - 2 : 0) * SCR_A;   // wavefront 0 factorises the chunk above it (so not over the factor blocks)
+        {                                          // wavefront 0 factorises the chunk above it (so not over the factor blocks); in the
+            const int na = (NHW > 2 ? NHW - 2 : 0) * SCR_A;     // row phases the same cells hold the sums of the stage groups: 8 groups x
+            o_z = o_scra2 + (na > ACC ? na : ACC);              // 32 lanes x (S1, S2)
+        }
         o_wc = o_z + (n1 + 1) * NZS;
         o_b = o_wc + n1 * NQP;
         o_bf = o_b + n1 * NX;
@@ -105,6 +109,15 @@ __device__ unsigned long long g_wg_prof[16];
 
 #ifndef QP_WG_CHUNK
 #define QP_WG_CHUNK 8      // stages per step of the assembly / factorisation overlap (phases A and B)
+#endif
+#ifndef QP_WG_RCH
+#define QP_WG_RCH 6        // stages per step of the roll-out / rows overlap (phases C and D, F and G)
+#endif
+#ifndef QP_WG_RND4
+#define QP_WG_RND4 2       // rounds of rows the two free half-waves of a 4-half-wave workgroup take per step of the roll-out
+#endif
+#ifndef QP_WG_RND8
+#define QP_WG_RND8 1       // the same for the six free half-waves of an 8-half-wave workgroup
 #endif
 typedef double v4d __attribute__((ext_vector_type(4)));
 // "These N values are needed HERE": one empty asm that lists them all -- the compiler then issues every load behind them before this
@@ -269,12 +282,6 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         for (int j = 1; j < NVG; j++) { if (j < NHW) m = fmax(m, sRed[4 * j]); a += sRed[4 * j + 1]; c += sRed[4 * j + 2]; }
         vmax = m; s1[0] = a; s2[0] = c;
         __syncthreads();
-    };
-    // this stage's group among the GPH of the half-wave
-    auto add_to_group = [&](double (&acc)[GPH], int k, double v) {
-        const int g_ = (k / NHW) % GPH;
-#pragma unroll
-        for (int g = 0; g < GPH; g++) acc[g] += (g_ == g) ? v : 0.0;
     };
 
     // where piece j of a stage's [Tt | Gt | gn | b | scalars] goes in the row-major scratch of the row phases (as in k_qp_ipm's
@@ -737,12 +744,14 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
 
         // roll-out through the factor blocks: z_k = [u_k | x_k] for every stage (wavefront 0).  Every operand of a stage is read in one
         // batch at its top; two hand-offs per stage (rho, then the state).
-        auto rollout = [&](auto corr_tag) {
+        auto rollout = [&](auto corr_tag, int k_lo, int k_hi) {
             constexpr bool CORR = decltype(corr_tag)::value;
             asm volatile("; WGMARK ROLL_BEGIN");
-            if (hl < NX) sZ[NU + hl] = dx0_reg;
-            lds_fence();
-            for (int k = 0; k < N; k++) {
+            if (k_lo == 0) {
+                if (hl < NX) sZ[NU + hl] = dx0_reg;
+                lds_fence();
+            }
+            for (int k = k_lo; k < k_hi; k++) {
                 const double* fk = sFac + k * NFW;
                 double* zk = sZ + k * NZS;
                 double wrow[NX + 2], xs[NX + 2], lt[NQ + 2];
@@ -799,20 +808,29 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 zk[z_dst_x] = hl < NQ ? xs[NX] + dt * xs[NX + 1] + cB * u + lt[NQ] : xs[NX] + dt * u + lt[NQ];
                 lds_fence();
             }
-            if (hl < NQ) sZ[N * NZS + hl] = 0.0;      // no control at the end stage
+            if (k_hi == N && hl < NQ) sZ[N * NZS + hl] = 0.0;      // no control at the end stage
             asm volatile("; WGMARK ROLL_END");
         };
-        // rows of every stage for the roll-out in sZ (stage-parallel): ratio test, sums; predictor: c.z_aff, a1 / a2; corrector: c.z+, z+
+        // Roll-out (wavefront 0) and the rows of every stage for it (ratio test, sums; predictor: c.z_aff, a1 / a2; corrector: c.z+, z+),
+        // overlapped the way phases A and B are: the roll-out advances by chunks of QP_WG_RCH stages with a workgroup barrier after
+        // each, and WHILE wavefront 0 rolls out a chunk the half-waves 2 .. NHW-1 take the rows of stages that are complete, RND
+        // rounds per step, in increasing stage order; what is left when the roll-out is through is shared by all half-waves.  Which
+        // half-wave takes which stage is a function of (N, NHW) alone.  The sums of a lane over the stages of a group (k mod 8) live
+        // in LDS cells, added in increasing k whoever processes the stage -- so they do not depend on the schedule or on NHW.
         auto rows_phase = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
-            double rr = 0.0, S1[GPH] = {}, S2[GPH] = {};
+            constexpr int NHELP = NHW - 2, RND = NHW == 4 ? QP_WG_RND4 : QP_WG_RND8, RCH = QP_WG_RCH;
+            static_assert(RND * NHELP <= NVG && RCH >= 1, "a step's stages must lie in different groups (their cells are shared)");
+            double rr = 0.0;
             double* const scr = dsm + Ls.o_scrd + hw * Ls.SCR_D;
             double* const sD = scr + Ls.d_D;
             double* const sE = scr + Ls.d_E;
             double* const sBS = scr + Ls.d_BS;
             double* const sCst = scr + Ls.d_CST;
+            dbl2* const sAcc = reinterpret_cast<dbl2*>(dsm + Ls.o_scra2);
             dbl2 Cs[CST_PF], qr0, qr1, qr2;
             double qcza = 0.0;
+            int k_pref = -1;                       // the stage whose records sit in (Cs, qr*, qcza)
             auto load_r = [&](int k) {
                 const double* w = ws + (size_t)k * Ly.stride;
                 const dbl2* s2 = reinterpret_cast<const dbl2*>(w + Ly.oIMG);
@@ -821,9 +839,11 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 qr0 = reinterpret_cast<const dbl2*>(w + Ly.oR0)[hr]; qr1 = reinterpret_cast<const dbl2*>(w + Ly.oR1)[hr];
                 qr2 = reinterpret_cast<const dbl2*>(w + Ly.oR2)[hr];
                 if (CORR) qcza = w[Ly.oCZA + hr];
+                k_pref = k;
             };
-            load_r(min(hw, N));
-            for (int k = hw; k <= N; k += NHW) {
+            // the rows of stage k; k_next: the stage this half-wave expects to take after it (requested now, a whole stage ahead)
+            auto do_stage = [&](int k, int k_next) {
+                if (k_pref != k) load_r(k);        // (an irregular step of the schedule: the request was for another stage)
                 double* w = ws + (size_t)k * Ly.stride;
                 const double* zk = sZ + k * NZS;
 #pragma unroll
@@ -833,7 +853,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 }
                 const dbl2 r0 = qr0, r1 = qr1, r2 = qr2;
                 const double cza = qcza;
-                load_r(min(k + NHW, N));       // (the next stage of this half-wave, a whole stage-round ahead)
+                load_r(k_next);
                 lds_fence();
                 {
                     const double* cr = sCst + hl_c * NZP;
@@ -861,8 +881,12 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                         w[Ly.oCZN + hr] = cz;
                         w[Ly.oZN + hz] = zk[hz];
                     }
-                    add_to_group(S1, k, row_live ? s1_ : 0.0);
-                    add_to_group(S2, k, row_live ? s2_ : 0.0);
+                    dbl2* const cell = sAcc + (k & (NVG - 1)) * 32 + hl;
+                    dbl2 acc = *cell;
+                    if (k < NVG) acc = dbl2{0.0, 0.0};       // (the first stage of its group: nothing to zero beforehand)
+                    acc.x += row_live ? s1_ : 0.0;
+                    acc.y += row_live ? s2_ : 0.0;
+                    *cell = acc;
                 }
                 if (!CORR) {
                     lds_fence();
@@ -893,15 +917,52 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                     if (hl < NZ) reinterpret_cast<dbl2*>(sA12 + k * 2 * NZP)[hz] = dbl2{a1, a2};
                 }
                 lds_fence();
+            };
+            // (two loops with the same number of barriers behind a branch the hardware takes as a whole wavefront: the registers that
+            //  carry a half-wave's requested records from step to step are then not alive inside the roll-out)
+            int hdone = 0;                         // stages whose rows are done (always the stages 0 .. hdone-1)
+            if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+                for (int k_lo = 0; k_lo < N; k_lo += RCH) {
+                    rollout(corr_tag, k_lo, min(k_lo + RCH, N));
+                    hdone += min(k_lo - hdone, RND * NHELP);
+                    __syncthreads();
+                }
+                load_r(min(hdone + hw, N));        // this half-wave's first stage of what is left
+            } else {
+                const int h = hw - 2;
+                load_r(min(h, N));
+                for (int k_lo = 0; k_lo < N; k_lo += RCH) {
+                    const bool last = k_lo + RCH >= N;
+                    const int n = min(k_lo - hdone, RND * NHELP);      // (stages below k_lo are rolled out)
+#pragma unroll
+                    for (int i = 0; i < RND; i++) {
+                        const int k = hdone + h + i * NHELP;
+                        if (k < hdone + n) {
+                            int kn = k + NHELP;
+                            if (i == RND - 1 || kn >= hdone + n) kn = hdone + n + (last ? hw : h);
+                            do_stage(k, min(kn, N));
+                        }
+                    }
+                    hdone += n;
+                    __syncthreads();
+                }
+            }
+            WGT(CORR ? 5 : 2);
+            for (int k = hdone + hw; k <= N; k += NHW) do_stage(k, min(k + NHW, N));
+            __syncthreads();
+            double S1[GPH], S2[GPH];
+#pragma unroll
+            for (int g = 0; g < GPH; g++) {
+                const int grp = hw + g * NHW;
+                const dbl2 v = sAcc[grp * 32 + hl];
+                S1[g] = grp <= N ? v.x : 0.0;
+                S2[g] = grp <= N ? v.y : 0.0;
             }
             block_reduce(rr, S1, S2);
             *rr_out = rr; *S1_out = S1[0]; *S2_out = S2[0];
         };
 
         // =============== phases C, D: predictor ============================================================================
-        if (seq) rollout(std::false_type{});
-        __syncthreads();
-        WGT(2);
         double rr_aff, S1, S2;
         rows_phase(std::false_type{}, &rr_aff, &S1, &S2);
         WGT(3);
@@ -991,9 +1052,6 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         __syncthreads();
         WGT(4);
         // =============== phases F, G: corrector =============================================================================
-        if (seq) rollout(std::true_type{});
-        __syncthreads();
-        WGT(5);
         double rr_max, S1c, S2c;
         rows_phase(std::true_type{}, &rr_max, &S1c, &S2c);
         WGT(6);
