@@ -37,8 +37,8 @@ out = s.solve(xd, xgd, ugd, pd)
 qp_ms = s.timing()['time_qp'] * 1e3
 L.smpc_debug_qp_wg_profile(buf)
 v = np.array(list(buf), dtype=np.float64)
-names = {0: 'A rows + H blocks (parallel)', 1: 'B Riccati recursion', 2: 'C predictor roll-out', 3: 'D rows (parallel)',
-         4: 'E corrector costate', 7: '  B: commit H, P b', 8: '  B: Lambda, G, rho', 9: '  B: Cholesky, columns', 10: '  B: P update, p', 5: 'F corrector roll-out', 6: 'G rows (parallel)', 12: 'epilogue', 13: 'prologue'}
+names = {0: 'A rows + H blocks (parallel)', 1: 'B Riccati recursion', 2: 'C predictor roll-out (+ D beside it)', 3: 'D rows left over (parallel)',
+         4: 'E corrector costate', 7: '  B: commit H, P b', 8: '  B: Lambda, G, rho', 9: '  B: Cholesky, columns', 10: '  B: P update, p', 5: 'F corrector roll-out (+ G beside it)', 6: 'G rows left over (parallel)', 12: 'epilogue', 13: 'prologue'}
 blocks, its = v[14], v[15]
 tot = v[:14].sum()
 print('B %d  QP (setup + ipm) %.3f ms  workgroups %d  mean iterations %.2f' % (B, qp_ms, blocks, its / max(blocks, 1)))
