@@ -110,8 +110,14 @@ __device__ unsigned long long g_wg_prof[16];
 #ifndef QP_WG_CHUNK
 #define QP_WG_CHUNK 8      // stages per step of the assembly / factorisation overlap (phases A and B)
 #endif
-#ifndef QP_WG_RCH
-#define QP_WG_RCH 6        // stages per step of the roll-out / rows overlap (phases C and D, F and G)
+#ifndef QP_WG_RCH4
+#define QP_WG_RCH4 6       // stages per step of the roll-out / rows overlap (phases C and D, F and G) in a 4-half-wave workgroup
+#endif
+#ifndef QP_WG_RCH8
+#define QP_WG_RCH8 6       // ... in an 8-half-wave workgroup
+#endif
+#ifndef QP_WG_SEQ_LANES
+#define QP_WG_SEQ_LANES 32 // lanes of wavefront 0 that run the roll-outs and the corrector's costate (written for 32; 64: the upper half mirrors)
 #endif
 #ifndef QP_WG_RND4
 #define QP_WG_RND4 2       // rounds of rows the two free half-waves of a 4-half-wave workgroup take per step of the roll-out
@@ -320,8 +326,6 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     constexpr int FS = WgLds<NQ>::FS, LCOL = WgLds<NQ>::LCOL, NFW = WgLds<NQ>::NFW, NZS = WgLds<NQ>::NZS;
     double* const sP = dsm + Ls.s_P;
     double* const sPv = dsm + Ls.s_pv;
-    double* const sR = dsm + Ls.s_R;
-    double* const sV = dsm + Ls.s_V;
     // [Lambda | G]: element e = ln + 64 t is  H_e + sum of four entries of P_{k+1} with fixed coefficients (B^T P B, B^T P A in closed form)
     int lgo[2][4], lgd[2][2];
     double lgc[2][4];
@@ -371,7 +375,6 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
     const int fac_col = hc <= NX ? hc : (hc >= LC0 && hc - LC0 < NQ ? LCOL + hc - LC0 : NX + 1);                        // this lane's column of the factor block (idle lanes: the pad)
     const int iu = hl_x < NQ ? hl_x : hl_x - NQ;                                            // control of the roll-out's lanes 0 .. NX-1
     const int z_dst_u = hl < NQ ? hl : NZP, z_dst_x = hl < NX ? NZS + NU + hl : NZP + 1;      // roll-out stores (idle lanes: the record's spare cells)
-    const int r_dst = hl < NQ ? hl : NQP;                                                   // hand-off cells of rho / L^-1 rho
     const int pv_dst_e = (hl >= NU && hl < NZ) ? hl - NU : NX;                               // corrector costate
 
     // ---- initial residual norm and complementarity from the setup partials ------------------------------------------------
@@ -668,14 +671,16 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                         for (int t = 0; t < j; t++) v = fma(-Lr[j][t], col[t], v);
                         col[j] = v * inv;
                     }
-#pragma unroll
-                    for (int i = 0; i < NQ; i++) fk[i * FS + fac_col] = col[i];
                 }
                 asm volatile("; WGMARK B_PUPD_BEGIN");
                 WGT(9);
-                if (k > 0) {
-                    double pr[4 * XR + 2];
-                    const int i_ = min(lc, NX - 1), i2_ = i_ >= NQ ? i_ - NQ : 0;
+                double pr[4 * XR + 2];
+                const int i_ = min(lc, NX - 1), i2_ = i_ >= NQ ? i_ - NQ : 0;
+                v4d ww = {0.0, 0.0, 0.0, 0.0};
+                double kc[NQ];
+                {
+                    // (at stage 0 too, where nothing uses them: a branch here would put the wait for the MFMAs in front of the
+                    //  back-substitution below)
 #pragma unroll
                     for (int r = 0; r < XR; r++)
 #pragma unroll
@@ -684,12 +689,33 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                     hold_n(pr);
                     // [W | w]^T [W | w] as a 16 x 16 tile: lane (g, c) of the result holds rows g, g + 4, ... of column c.  A = B: the lanes of
                     // groups 0 and 2 (which hold the same columns, c = their lane in the group) feed two k-slices per instruction
-                    v4d ww = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int m = 0; m < (NQ + 1) / 2; m++) {
                         const double av = 2 * m + 1 < NQ ? fma(col[2 * m + 1 < NQ ? 2 * m + 1 : 0], mfa1, col[2 * m] * mfa0) : col[2 * m] * mfa0;
                         ww = __builtin_amdgcn_mfma_f64_16x16x4f64(av, av, ww, 0, 0, 0);
                     }
+                }
+                // What the roll-outs and the corrector's costate read is L^-T times this lane's column: the feedback gain K = L^-T W,
+                // k = L^-T w, and, from the columns of L^-1, Lambda^-1 -- a back-substitution in registers, column-oriented (every
+                // finished entry is taken out of all rows above it at once: a chain of 2 NQ - 1 dependent operations instead of
+                // NQ (NQ + 1) / 2; nothing hides it -- the f64 MFMA runs on the FP64 pipeline of the vector unit, 78.6 TFLOP/s either way).
+                // With it a roll-out's stage is u = -(K x + k), x+ = A x + B u + b with ONE hand-off (the state): lane i needs row
+                // i mod NQ of K only; the costate's stage needs column i of K and a row of Lambda^-1 (the factored form
+                // L^-T (W x + w) of k_qp_ipm costs a hand-off more per stage in each of the three recursions).
+                {
+                    double v[NQ];
+#pragma unroll
+                    for (int i = 0; i < NQ; i++) v[i] = col[i];
+#pragma unroll
+                    for (int t = NQ - 1; t >= 0; t--) {
+                        kc[t] = v[t] * Linv[t];
+#pragma unroll
+                        for (int i = 0; i < t; i++) v[i] = fma(-Lr[t][i], kc[t], v[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NQ; i++) fk[i * FS + fac_col] = kc[i];
+                if (k > 0) {
                     // P_k = Hxx + A^T P A - W^T W,  p_k = gh_x + A^T (p + P b) - W^T w
                     double pb1 = 0.0, pb2 = 0.0;
                     if (bfl) {
@@ -742,8 +768,9 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         }
         if (sFlag[0] != 0.0) { st_code = 4; pending = false; break; }
 
-        // roll-out through the factor blocks: z_k = [u_k | x_k] for every stage (wavefront 0).  Every operand of a stage is read in one
-        // batch at its top; two hand-offs per stage (rho, then the state).
+        // roll-out through the gains: z_k = [u_k | x_k] for every stage (wavefront 0).  Every operand of a stage is read in one batch at
+        // its top; lane i (state entry i) forms the control of its joint, u = -(K x + k [+ Lambda^-1 r of the corrector]), from row
+        // i mod NQ of [K | k] by itself, so the only hand-off of a stage is the state.
         auto rollout = [&](auto corr_tag, int k_lo, int k_hi) {
             constexpr bool CORR = decltype(corr_tag)::value;
             asm volatile("; WGMARK ROLL_BEGIN");
@@ -754,13 +781,13 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
             for (int k = k_lo; k < k_hi; k++) {
                 const double* fk = sFac + k * NFW;
                 double* zk = sZ + k * NZS;
-                double wrow[NX + 2], xs[NX + 2], lt[NQ + 2];
-                if constexpr (NQ % 2 == 0) {
+                double krow[NX + 2], xs[NX], ex[4];
 #pragma unroll
-                    for (int j = 0; j < (NX + 2) / 2; j++) {
-                        const dbl2 v = reinterpret_cast<const dbl2*>(fk + hl_u * FS)[j];
-                        wrow[2 * j] = v.x; wrow[2 * j + 1] = v.y;
-                    }
+                for (int j = 0; j < (NX + 2) / 2; j++) {
+                    const dbl2 v = reinterpret_cast<const dbl2*>(fk + iu * FS)[j];       // row iu of [K | k | pad]
+                    krow[2 * j] = v.x; krow[2 * j + 1] = v.y;
+                }
+                if constexpr (NQ % 2 == 0) {
 #pragma unroll
                     for (int j = 0; j < NX / 2; j++) {
                         const dbl2 v = reinterpret_cast<const dbl2*>(zk + NU)[j];
@@ -768,44 +795,21 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j <= NX; j++) wrow[j] = fk[hl_u * FS + j];
-#pragma unroll
                     for (int j = 0; j < NX; j++) xs[j] = zk[NU + j];
                 }
-                xs[NX] = zk[NU + hl_x]; xs[NX + 1] = zk[NU + NQ + iu];
+                ex[0] = zk[NU + hl_x]; ex[1] = zk[NU + NQ + iu];
+                ex[2] = sBk[k * NX + hl_x];
+                ex[3] = CORR ? sWC[k * NQP + iu] : 0.0;
+                hold_n(krow); hold_n(xs); hold_n(ex);
+                double a = krow[NX] + ex[3], a_v = 0.0;
 #pragma unroll
-                for (int j = 0; j < NQ; j++) lt[j] = fk[j * FS + LCOL + iu];      // column iu of L^-1 (its zeros included)
-                lt[NQ] = sBk[k * NX + hl_x];
-                lt[NQ + 1] = CORR ? sWC[k * NQP + hl_u] : 0.0;
-                hold_n(wrow); hold_n(xs); hold_n(lt);
-                {
-                    double a = wrow[NX] + lt[NQ + 1], a_v = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NQ; j++) {
-                        a = fma(wrow[j], xs[j], a);
-                        a_v = fma(wrow[NQ + j], xs[NQ + j], a_v);
-                    }
-                    sR[r_dst] = a + a_v;
+                for (int j = 0; j < NQ; j++) {
+                    a = fma(krow[j], xs[j], a);
+                    a_v = fma(krow[NQ + j], xs[NQ + j], a_v);
                 }
-                lds_fence();
-                double rh[NQP];
-                if constexpr (NQ % 2 == 0) {
-#pragma unroll
-                    for (int j = 0; j < NQ / 2; j++) {
-                        const dbl2 v = reinterpret_cast<const dbl2*>(sR)[j];
-                        rh[2 * j] = v.x; rh[2 * j + 1] = v.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NQ; j++) rh[j] = sR[j];
-                }
-                hold_n(rh);
-                double s_ = 0.0;
-#pragma unroll
-                for (int j = 0; j < NQ; j++) s_ = fma(lt[j], rh[j], s_);
-                const double u = -s_;
+                const double u = -(a + a_v);
                 zk[z_dst_u] = u;
-                zk[z_dst_x] = hl < NQ ? xs[NX] + dt * xs[NX + 1] + cB * u + lt[NQ] : xs[NX] + dt * u + lt[NQ];
+                zk[z_dst_x] = hl < NQ ? ex[0] + dt * ex[1] + cB * u + ex[2] : ex[0] + dt * u + ex[2];
                 lds_fence();
             }
             if (k_hi == N && hl < NQ) sZ[N * NZS + hl] = 0.0;      // no control at the end stage
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         // in LDS cells, added in increasing k whoever processes the stage -- so they do not depend on the schedule or on NHW.
         auto rows_phase = [&](auto corr_tag, double* rr_out, double* S1_out, double* S2_out) {
             constexpr bool CORR = decltype(corr_tag)::value;
-            constexpr int NHELP = NHW - 2, RND = NHW == 4 ? QP_WG_RND4 : QP_WG_RND8, RCH = QP_WG_RCH;
+            constexpr int NHELP = NHW - 2, RND = NHW == 4 ? QP_WG_RND4 : QP_WG_RND8, RCH = NHW == 4 ? QP_WG_RCH4 : QP_WG_RCH8;
             static_assert(RND * NHELP <= NVG && RCH >= 1, "a step's stages must lie in different groups (their cells are shared)");
             double rr = 0.0;
             double* const scr = dsm + Ls.o_scrd + hw * Ls.SCR_D;
@@ -923,7 +927,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
             int hdone = 0;                         // stages whose rows are done (always the stages 0 .. hdone-1)
             if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
                 for (int k_lo = 0; k_lo < N; k_lo += RCH) {
-                    rollout(corr_tag, k_lo, min(k_lo + RCH, N));
+                    if (tid < QP_WG_SEQ_LANES) rollout(corr_tag, k_lo, min(k_lo + RCH, N));
                     hdone += min(k_lo - hdone, RND * NHELP);
                     __syncthreads();
                 }
@@ -974,76 +978,63 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
         corr_w = a_aff >= 0.3 ? 1.0 : a_aff * a_aff;
 
         // =============== phase E: corrector costate (wavefront 0) =========================================================
-        // (every operand of a stage read in one batch at its top; hand-offs: rho, L^-1 rho, the costate -- in place)
-        if (seq) {
+        // Its gradient sigma mu a1 + cw a2 first, for every stage at once (all threads): the control part into the corrector's cells,
+        // the state part over a1.  Then the recursion p_k = gh_x + A^T p - K^T r, r = gh_u + B^T p, with the control offset of the
+        // corrector's roll-out, Lambda^-1 r, on the way: every lane forms r by itself from the costate it has read anyway, so the one
+        // hand-off of a stage is the costate (in place).
+        for (int idx = tid; idx < (N + 1) * NZ; idx += NT) {
+            const int k = idx / NZ, c = idx - k * NZ;
+            const dbl2 a12 = reinterpret_cast<const dbl2*>(sA12 + k * 2 * NZP)[c];
+            const double gh = sigmu * a12.x + corr_w * a12.y;
+            if (c < NU) { if (k < N) sWC[k * NQP + c] = gh; }
+            else sA12[(k * NZP + c) * 2] = gh;
+        }
+        __syncthreads();
+        if (tid < QP_WG_SEQ_LANES) {
             asm volatile("; WGMARK E_BEGIN");
             const int ip1 = hl < NU ? hl : hl_px;
             const int ip2 = hl < NU ? NQ + hl : (hl_px >= NQ ? hl_px - NQ : 0);
-            {
-                const dbl2 a12 = reinterpret_cast<const dbl2*>(sA12 + N * 2 * NZP)[hz];
-                sPv[pv_dst_e] = sigmu * a12.x + corr_w * a12.y;
-            }
+            double* const wc_dst = hl < NQ ? sWC + hl : sPv + NX + 1;        // (idle lanes: the costate's spare cell)
+            const int wc_str = hl < NQ ? NQP : 0;
+            sPv[pv_dst_e] = sA12[(N * NZP + hz) * 2];
             lds_fence();
             for (int k = N - 1; k >= 0; k--) {
                 const double* fk = sFac + k * NFW;
-                double t_[2 * NQP + 4];
-                {
-                    const dbl2 a_ = reinterpret_cast<const dbl2*>(sA12 + k * 2 * NZP)[hz];
-                    t_[2 * NQP] = a_.x; t_[2 * NQP + 1] = a_.y;
+                double pv[NX], gu[NQP], kcl[NQ], lam[NQ], ex[3];
+#pragma unroll
+                for (int j = 0; j < NX / 2; j++) {
+                    const dbl2 v = reinterpret_cast<const dbl2*>(sPv)[j];
+                    pv[2 * j] = v.x; pv[2 * j + 1] = v.y;
                 }
-                t_[2 * NQP + 2] = sPv[ip1]; t_[2 * NQP + 3] = sPv[ip2];
+#pragma unroll
+                for (int j = 0; j < NQP / 2; j++) {
+                    const dbl2 v = reinterpret_cast<const dbl2*>(sWC + k * NQP)[j];
+                    gu[2 * j] = v.x; gu[2 * j + 1] = v.y;
+                }
+#pragma unroll
+                for (int t = 0; t < NQ; t++) kcl[t] = fk[t * FS + hl_px];                           // column hl_px of K
                 if constexpr (NQ % 2 == 0) {
 #pragma unroll
                     for (int j = 0; j < NQ / 2; j++) {
-                        const dbl2 v = reinterpret_cast<const dbl2*>(fk + hl_u * FS + LCOL)[j];      // row hl_u of L^-1
-                        t_[2 * j] = v.x; t_[2 * j + 1] = v.y;
+                        const dbl2 v = reinterpret_cast<const dbl2*>(fk + hl_u * FS + LCOL)[j];      // row hl_u of Lambda^-1
+                        lam[2 * j] = v.x; lam[2 * j + 1] = v.y;
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) t_[j] = fk[hl_u * FS + LCOL + j];
+                    for (int j = 0; j < NQ; j++) lam[j] = fk[hl_u * FS + LCOL + j];
                 }
+                ex[0] = sA12[(k * NZP + hz) * 2]; ex[1] = sPv[ip1]; ex[2] = sPv[ip2];
+                hold_n(pv); hold_n(gu); hold_n(kcl); hold_n(lam); hold_n(ex);
+                double kr = 0.0, lr = 0.0;
 #pragma unroll
-                for (int t = 0; t < NQ; t++) t_[NQP + t] = fk[t * FS + hl_px];                       // column hl_px of W
-                hold_n(t_);
-                const double gh = sigmu * t_[2 * NQP] + corr_w * t_[2 * NQP + 1];
-                const double q1 = t_[2 * NQP + 2], q2 = t_[2 * NQP + 3];
-                sR[r_dst] = gh + cB * q1 + dt * q2;
-                lds_fence();
-                double rh[NQP];
-                if constexpr (NQ % 2 == 0) {
-#pragma unroll
-                    for (int j = 0; j < NQ / 2; j++) {
-                        const dbl2 v = reinterpret_cast<const dbl2*>(sR)[j];
-                        rh[2 * j] = v.x; rh[2 * j + 1] = v.y;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NQ; j++) rh[j] = sR[j];
+                for (int j = 0; j < NQ; j++) {
+                    const double r = gu[j] + cB * pv[j] + dt * pv[NQ + j];
+                    kr = fma(kcl[j], r, kr);
+                    lr = fma(lam[j], r, lr);
                 }
-                hold_n(rh);
-                double v = 0.0;
-#pragma unroll
-                for (int j = 0; j < NQ; j++) v = fma(t_[j], rh[j], v);
-                sV[r_dst] = v;
-                if (hl < NQ) sWC[k * NQP + hl] = v;
+                wc_dst[k * wc_str] = lr;
                 if (k > 0) {
-                    lds_fence();
-                    double wv[NQP];
-                    if constexpr (NQ % 2 == 0) {
-#pragma unroll
-                        for (int j = 0; j < NQ / 2; j++) {
-                            const dbl2 x_ = reinterpret_cast<const dbl2*>(sV)[j];
-                            wv[2 * j] = x_.x; wv[2 * j + 1] = x_.y;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < NQ; j++) wv[j] = sV[j];
-                    }
-                    hold_n(wv);
-                    double pk = gh + (hl_px < NQ ? q1 : dt * q2 + q1);
-#pragma unroll
-                    for (int t = 0; t < NQ; t++) pk = fma(-t_[NQP + t], wv[t], pk);
-                    sPv[pv_dst_e] = pk;
+                    sPv[pv_dst_e] = ex[0] + (hl_px < NQ ? ex[1] : dt * ex[2] + ex[1]) - kr;
                     lds_fence();
                 }
             }
