@@ -7,24 +7,26 @@
 //     rows: apply the step, barrier weights D, e;  H + C^T D C and g + C^T e of the stage;  c.z, ratio test, C^T e1, C^T e2.
 // Here ONE WORKGROUP (NHW half-wavefronts) owns an instance.  Per iteration:
 //   A  stage-parallel (half-wave h takes stages h, h + NHW, ...): rows + the stage's P-independent blocks -> "H record" (HBM / L2)
-//   B  wavefront 0: Riccati recursion  Lambda = Huu + B^T P B, G, Cholesky, [W | w], L^-1 -> factor blocks (LDS), P_k, p_k
-//   C  wavefront 0: predictor roll-out through the factors (LDS -> z in LDS)
+//   B  wavefront 0: Riccati recursion  Lambda = Huu + B^T P B, G, Cholesky, [W | w], P_k, p_k; then the gains K = L^-T W, k = L^-T w
+//      and Lambda^-1 (a back-substitution in registers) -> factor blocks (LDS)
+//   C  wavefront 0: predictor roll-out u = -(K x + k) (LDS -> z in LDS; one hand-off per stage: the state)
 //   D  stage-parallel: c.z_aff, ratio test, e1 / e2, a1 = C^T e1, a2 = C^T e2 (LDS)
-//   E  wavefront 0: corrector costate (touches only LDS)
+//   E  all threads: the corrector's gradient of every stage; wavefront 0: corrector costate (touches only LDS; one hand-off per stage)
 //   F  wavefront 0: corrector roll-out
 //   G  stage-parallel: c.z+, ratio test, z+ -> workspace
-// with a workgroup barrier between phases and the step-length logic replicated on every lane; A and B overlap by chunks of eight
-// stages (wavefront 0 factorises a chunk while the other half-waves assemble the one below it).  The sequential phases keep the
-// factor blocks, the defects, a1 / a2 and the roll-out in LDS: no HBM round trip sits on their chains any more.
+// with a workgroup barrier between phases and the step-length logic replicated on every lane.  A and B overlap by chunks of eight
+// stages (wavefront 0 factorises a chunk while the other half-waves assemble the one below it), D runs beside C and G beside F by
+// chunks of six (the other half-waves take the rows of stages that are rolled out already).  The sequential phases keep the factor
+// blocks, the defects, a1 / a2 and the roll-out in LDS: no HBM round trip sits on their chains any more.
 // SAME algorithm, SAME workspace records (written by k_stage_build / k_qp_setup, QpLayout) and the same per-row arithmetic
 // (qp_row_dir / qp_row_coeff of kernel_qp.hpp) as k_qp_ipm; only the order of a few sums differs (the x-x block is assembled before
-// the recursion instead of inside the P update, [W | w]^T [W | w] comes from the f64 MFMA, complementarity sums are taken in eight
-// groups of stages), so the two kernels agree to rounding, iterate for iterate (tests/test_gpu_parity.py::test_qp_kernels_agree).
+// the recursion instead of inside the P update, [W | w]^T [W | w] comes from the f64 MFMA, the control is -(K x + k) with the gain
+// formed explicitly instead of -L^-T (W x + w), complementarity sums are taken in eight groups of stages), so the two kernels agree to rounding, iterate for iterate (tests/test_gpu_parity.py::test_qp_kernels_agree).
 // What bounds ONE wavefront is its instruction count -- one instruction per ~5 clocks whatever it is, an LDS hand-off 83 clocks, a
 // dependent f64 MFMA 80 (scripts/lat_probe.hip, profiles/r06_lat_probe.txt) -- so the recursions are written for few instructions:
 // lane-dependent addresses formed once, reads batched behind one wait (hold_n), in-place updates, zeros stored instead of masks.
 // The engine picks per launch (engine.hip: qp_wg_choice; smpc_set_qp_mode): this form up to 1024 instances, k_qp_ipm for throughput.
-// DESIGN.md section 4c has the measurements (156 k clocks per IPM iteration of a lone instance against k_qp_ipm's 447 k).
+// DESIGN.md section 4c has the measurements (143 k clocks per IPM iteration of a lone instance against k_qp_ipm's 447 k).
 // Reference: controller.py:97-110, 136-167 (the QP HPIPM solves inside acados' RTI step).
 #pragma once
 #include "kernel_qp.hpp"
@@ -49,15 +51,16 @@ template <int NQ> struct HRecLayout {
 template <int NQ> struct WgLds {
     using LyT = QpLayout<NQ>;
     static constexpr int NX = 2 * NQ, NZ = 3 * NQ, NZP = LyT::NZP, NQP = LyT::NQP, WS2 = LyT::WS2;
-    // factor block of a stage as this kernel keeps it in LDS: NQ rows of [W | w | pad | L^-1], row-major -- the column solve's lanes
-    // store with one base address and immediate offsets, the roll-outs read row i of [W | w] and the corrector row i of L^-1 as whole
-    // 16-byte pieces, and L^-1 carries its zeros (no masks in the recursions)
+    // factor block of a stage as this kernel keeps it in LDS: NQ rows of [K | k | pad | Lambda^-1], row-major (K = L^-T W, k = L^-T w,
+    // Lambda^-1 = L^-T L^-1: what the Riccati lanes' columns of [W | w | L^-1] become under the back-substitution) -- those lanes
+    // store with one base address and immediate offsets, the roll-outs read row i of [K | k] and the corrector row i of Lambda^-1
+    // as whole 16-byte pieces
     static constexpr int LCOL = NX + 2, FS = qp_even_c(NX + 2 + NQ), NFW = NQ * FS;
     static constexpr int NZS = NZP + 2;        // roll-out record of a stage: [u | x | two cells that absorb the stores of idle lanes]
     static constexpr int ACC = 8 * 32 * 2;     // accumulator cells of the row phases (aliased over the assembling half-waves' scratch)
     int MRP, NRC, SCR_A, SCR_D, CST;
     int o_fac, o_a12, o_scrd, o_scra2, o_z, o_wc, o_b, o_bf, o_seq;
-    int s_P, s_pv, s_lam, s_G, s_R, s_V, s_red, s_part, s_flag;
+    int s_P, s_pv, s_lam, s_G, s_red, s_part, s_flag;
     int total;
     // scratch of a half-wave in phase A: [image | D | E | TD | GD]; in phases D / G: [D | E | b, scalars | row-major general rows | dump]
     int a_D, a_E, a_TD, a_GD;
@@ -90,8 +93,6 @@ template <int NQ> struct WgLds {
         s_pv = s; s += NX + 2;               // (+ a cell for the stores of idle lanes)
         s_lam = s; s += qp_even_c(NQ * NQ);
         s_G = s; s += NQ * WS2;
-        s_R = s; s += NQP + 2;               // rho of a stage (hand-off inside the roll-outs / the corrector's recursion) + dump
-        s_V = s; s += NQP + 2;               // L^-1 rho of the corrector's recursion + dump
         s_part = s; s += qp_even_c(n1);      // complementarity sum of every stage (phase A)
         s_red = s; s += 4 * 8;               // (eight groups whatever the workgroup size: block_reduce)
         s_flag = s; s += 2;
