@@ -861,18 +861,34 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 load_r(k_next);
                 lds_fence();
                 {
+                    // (every LDS operand of the row's value in ONE batch: the row of the Jacobian image, the stage's z, the soft weight, this
+                    //  lane's own state entry, its sum cell -- left alone the compiler makes three or four round trips of them)
                     const double* cr = sCst + hl_c * NZP;
+                    dbl2* const cell = sAcc + (k & (NVG - 1)) * 32 + hl;
+                    double cv[NZ], zv[NZ], ex[5];
+#pragma unroll
+                    for (int j = 0; j < NZ / 2; j++) {
+                        const dbl2 v = reinterpret_cast<const dbl2*>(cr)[j], z2 = reinterpret_cast<const dbl2*>(zk)[j];
+                        cv[2 * j] = v.x; cv[2 * j + 1] = v.y;
+                        zv[2 * j] = z2.x; zv[2 * j + 1] = z2.y;
+                    }
+                    if constexpr (NZ % 2) { cv[NZ - 1] = cr[NZ - 1]; zv[NZ - 1] = zk[NZ - 1]; }
+                    {
+                        const dbl2 acc0 = *cell;
+                        ex[0] = sBS[NX + 2]; ex[1] = zk[NU + hl_x]; ex[2] = acc0.x; ex[3] = acc0.y; ex[4] = zk[hz];
+                    }
+                    hold_n(cv); hold_n(zv); hold_n(ex);
                     double a = 0.0, a_q = 0.0, a_v = 0.0;
 #pragma unroll
                     for (int c = 0; c < NQ; c++) {
-                        a = fma(cr[c], zk[c], a);
-                        a_q = fma(cr[NU + c], zk[NU + c], a_q);
-                        a_v = fma(cr[NU + NQ + c], zk[NU + NQ + c], a_v);
+                        a = fma(cv[c], zv[c], a);
+                        a_q = fma(cv[NU + c], zv[NU + c], a_q);
+                        a_v = fma(cv[NU + NQ + c], zv[NU + NQ + c], a_v);
                     }
                     a += a_q + a_v;
-                    const double cz = hr < NX ? zk[NU + hl_x] : a;
+                    const double cz = hr < NX ? ex[1] : a;
                     const QpRow rs{r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
-                    const double wsoft = sBS[NX + 2];
+                    const double wsoft = ex[0];
                     const bool soft = soft_lane && wsoft >= 0.0;
                     double s1_ = 0.0, s2_ = 0.0;
                     if (!CORR) {
@@ -884,10 +900,9 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                     } else {
                         qp_row_dir<false>(rs, soft, wsoft, cz, sigmu, corr_w, cza, &rr, &s1_, &s2_, nullptr, nullptr);
                         w[Ly.oCZN + hr] = cz;
-                        w[Ly.oZN + hz] = zk[hz];
+                        w[Ly.oZN + hz] = ex[4];
                     }
-                    dbl2* const cell = sAcc + (k & (NVG - 1)) * 32 + hl;
-                    dbl2 acc = *cell;
+                    dbl2 acc = dbl2{ex[2], ex[3]};
                     if (k < NVG) acc = dbl2{0.0, 0.0};       // (the first stage of its group: nothing to zero beforehand)
                     acc.x += row_live ? s1_ : 0.0;
                     acc.y += row_live ? s2_ : 0.0;
@@ -895,10 +910,12 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                 }
                 if (!CORR) {
                     lds_fence();
-                    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+                    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0, xd[2];
                     {
                         constexpr int RH = (NRC_MAX + 1) / 2;
                         double cc[RH], d1[RH], d2[RH];
+                        const int ixd = hz >= NU ? hz - NU : 0;
+                        xd[0] = sD[ixd]; xd[1] = sE[ixd];
 #pragma unroll
                         for (int hh = 0; hh < 2; hh++) {
 #pragma unroll
@@ -908,6 +925,8 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                                 d1[r] = sD[NX + rr_];
                                 d2[r] = sE[NX + rr_];
                             }
+                            hold_n(cc); hold_n(d1); hold_n(d2);
+                            if (hh == 0) hold_n(xd);
 #pragma unroll
                             for (int r = 0; r < RH; r++) {
                                 const bool on = hh * RH + r < NRC && hh * RH + r < NRC_MAX;
@@ -918,7 +937,7 @@ __global__ __launch_bounds__(32 * NHW) __attribute__((amdgpu_waves_per_eu(QP_WG_
                     }
                     a1 += b1;
                     a2 += b2;
-                    if (hz >= NU) { a1 += sD[hz - NU]; a2 += sE[hz - NU]; }
+                    if (hz >= NU) { a1 += xd[0]; a2 += xd[1]; }
                     if (hl < NZ) reinterpret_cast<dbl2*>(sA12 + k * 2 * NZP)[hz] = dbl2{a1, a2};
                 }
                 lds_fence();
