@@ -483,8 +483,8 @@ int launch_stage_records(smpc_handle* h, int B, const double* x0, const double* 
 // workgroup (four wavefronts, one per SIMD: one workgroup per CU -- up to qp_wg_full_batch instances run in one round) and with 4
 // (two wavefronts: two workgroups per CU, the stage-parallel phases take twice the rounds -- 512 instances in one round, up to
 // qp_wg_max_batch = 1024 in one launch whose later workgroups start as the first ones retire).  Above that k_qp_ipm's two instances per
-// wavefront use the chip better (per step, latency form against k_qp_ipm: 1.08 ms against 2.16 at 512 instances, 1.45 against 2.27 at
-// 1024 as two sub-batches of 512, 2.13 against 2.46 at 1536 as three; from 2048 on k_qp_ipm wins -- DESIGN.md section 4c).  A handle
+// wavefront use the chip better (per step, latency form against k_qp_ipm: 0.99 ms against 2.16 at 512 instances, 1.37 against 2.27 at
+// 1024 as two sub-batches of 512, 2.06 against 2.46 at 1536 as three; from 2048 on k_qp_ipm wins -- DESIGN.md section 4c).  A handle
 // only sees its own launch: a caller that spreads ONE batch over several handles should pick the form from the total (bench.py does:
 // the latency form up to 1536 instances per GPU in sub-batches of at most 512).
 #ifndef QP_WG_FULL_BATCH
